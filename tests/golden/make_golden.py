@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference lives at /root/reference and does not travel to the GPU box; only the small .npz
+files written here do.  Inputs (noise, images, masks, probe vectors) are stored next to the
+reference's outputs, so neither RNG streams nor the reference are needed to replay a case.
+
+Stand-ins installed before importing the reference (packages that are simply not installed here):
+  torch_dct   -> scipy.fft.dctn/idctn(norm='ortho')   (arithmetic path: the DCT boundary is therefore
+                                                        pinned against SciPy only)
+  torchvision -> module exposing `.torch` (measurements.py:7 does `from torchvision import torch`)
+  hdf5storage -> scipy.io.loadmat (MATLAB-v5 kernel file)
+  pywt, lpips, skimage, hydra, omegaconf, ddnm_functions.custom_ddnm_sampling -> empty (never called)
+Two patches for reference defects: a placeholder `CovarianceHessianBFGSDCTPCA`
+(conditioning_mechanisms.py:188 imports a class that is defined nowhere) and `Tensor.cuda()` as a
+no-op (hard-coded .cuda() in online_update_bfgs.py:40-51 and the customcuda solvers).
+"""
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import scipy.fft
+import scipy.io
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+os.chdir(REF)  # the reference opens ./measurement_utils/kernels/... and analytic_variance/... relative to cwd
+
+
+def _install_standins():
+    td = types.ModuleType("torch_dct")
+    td.dct_2d = lambda x, norm=None: torch.from_numpy(
+        scipy.fft.dctn(x.detach().cpu().numpy(), type=2, axes=(-2, -1), norm="ortho")).to(x.dtype)
+    td.idct_2d = lambda x, norm=None: torch.from_numpy(
+        scipy.fft.idctn(x.detach().cpu().numpy(), type=2, axes=(-2, -1), norm="ortho")).to(x.dtype)
+    sys.modules["torch_dct"] = td
+    tv = types.ModuleType("torchvision")
+    tv.torch = torch
+    sys.modules["torchvision"] = tv
+    h5 = types.ModuleType("hdf5storage")
+    h5.loadmat = scipy.io.loadmat
+    sys.modules["hdf5storage"] = h5
+    for name in ("pywt", "lpips", "skimage", "skimage.metrics", "hydra", "omegaconf"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["omegaconf"].DictConfig = dict
+    sys.modules["omegaconf"].OmegaConf = object
+    ddnm = types.ModuleType("ddnm_functions.custom_ddnm_sampling")
+    ddnm.ddnm_conditional_sampler = None
+    sys.modules["ddnm_functions.custom_ddnm_sampling"] = ddnm
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+_install_standins()
+warnings.filterwarnings("ignore")
+import conditioning_utils.online_update_bfgs as ref_cov  # noqa: E402
+
+ref_cov.CovarianceHessianBFGSDCTPCA = type("CovarianceHessianBFGSDCTPCA", (), {})
+import conditioning_utils.conditioning_mechanisms as ref_cm  # noqa: E402
+import conditioning_utils.cg as ref_cg  # noqa: E402
+import generate_conditional as ref_gc  # noqa: E402
+import measurement_utils.measurements as ref_meas  # noqa: E402
+from measurement_utils.resizer import Resizer  # noqa: E402
+from training.openai_preconditioning import iDDPMLinearPrecond  # noqa: E402
+from training.openai_util import create_model  # noqa: E402
+
+from oracle.unet_oracle import UNetConfig, seeded_state  # noqa: E402  (weights recipe + config only)
+sys.path.insert(0, HERE)
+from inputs import SMALL_A, SMALL_B, randn, rng, script as _script, smooth_image  # noqa: E402
+
+F64 = torch.float64
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"wrote {name}.npz  ({os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024:.0f} KiB)")
+
+
+# ------------------------------------------------------------------ UNet helpers
+def ref_unet(cfg: UNetConfig, seed):
+    model = create_model(image_size=cfg.image_size, num_channels=cfg.num_channels,
+                         num_res_blocks=cfg.num_res_blocks,
+                         channel_mult=",".join(str(c) for c in cfg.channel_mult) if cfg.channel_mult else "",
+                         learn_sigma=cfg.learn_sigma, attention_resolutions=cfg.attention_resolutions,
+                         num_heads=cfg.num_heads, num_head_channels=cfg.num_head_channels,
+                         use_scale_shift_norm=cfg.use_scale_shift_norm, resblock_updown=cfg.resblock_updown,
+                         use_new_attention_order=cfg.use_new_attention_order)
+    if not cfg.conv_resample:
+        raise NotImplementedError
+    model.load_state_dict(seeded_state(cfg, seed), strict=True)  # proves key names + shapes match the reference
+    model.eval()
+    return model
+
+
+def ref_net(cfg, seed):
+    m = ref_unet(cfg, seed)
+    return iDDPMLinearPrecond(m, img_resolution=cfg.image_size, img_channels=3, label_dim=0)
+
+
+def cfg_dict(cfg):
+    return np.array(repr(cfg))
+
+
+# ------------------------------------------------------------------ 1. sigma grids (a2)
+def gold_sigma():
+    net = iDDPMLinearPrecond(None, 256, 3)
+    out = {"u": net.u}
+    for n in (10, 30, 100):
+        idx = torch.arange(n, dtype=F64)
+        smin, smax = max(0.002, net.sigma_min), min(80.0, net.sigma_max)
+        steps = ref_gc.get_sigma_steps("edm", n, smin, smax, None, None, 7, idx, 1000, 0.001, 0.008,
+                                       torch.zeros(1), None, None, 1e-3)
+        out[f"raw_{n}"] = steps
+        out[f"t_{n}"] = torch.cat([net.round_sigma(steps), torch.zeros(1, dtype=F64)])
+        out[f"idx_{n}"] = net.round_sigma(steps, return_index=True)
+    save("sigma_grids", **out)
+
+
+# ------------------------------------------------------------------ 2. UNet + precond + VJP (a3-a5)
+def gold_unet():
+    for tag, cfg, seed in (("unet_a", SMALL_A, 11), ("unet_b", SMALL_B, 12)):
+        net = ref_net(cfg, seed)
+        x = randn((1, 3, 64, 64), seed + 100) * 3.0
+        out = {"cfg": cfg_dict(cfg), "seed": seed}  # x = randn((1,3,64,64), seed+100)*3, cot_j = randn(D.shape, seed+200+j)
+        for j, sig in enumerate((40.0, 2.5, 0.05)):
+            sigma = torch.tensor(sig, dtype=F64)
+            xt = x.clone().requires_grad_()
+            if cfg.learn_sigma:
+                D, var = net(xt, sigma)
+                out[f"x0_var_{j}"] = var
+            else:  # precond needs 6 channels for x0_var; exercise the raw model only
+                c_in = 1 / (sigma ** 2 + 1).sqrt()
+                idx = net.round_sigma(sigma.reshape(1), return_index=True)
+                D = xt.float() - sigma.float() * net.model((c_in.float() * xt.float()),
+                                                           (1000 - idx).long().flatten())
+            cot = randn(D.shape, seed + 200 + j).to(D.dtype)
+            (vjp,) = torch.autograd.grad((cot * D).sum(), xt)
+            with torch.no_grad():
+                c_in = 1 / (sigma ** 2 + 1).sqrt()
+                idx = net.round_sigma(sigma.reshape(1), return_index=True)
+                raw = net.model(c_in.float() * x.float(), (1000 - idx).long().flatten())
+            out.update({f"sigma_{j}": sig, f"raw_{j}": raw, f"D_{j}": D, f"vjp_{j}": vjp,
+                        f"tstep_{j}": (1000 - idx)})
+        save(tag, **out)
+
+
+# ------------------------------------------------------------------ 3. covariance object (a7-a10)
+def _mk_cov(kind, d, sigma0_sq, shape=None, data_dir=None, **kw):
+    if kind == "identity":
+        return ref_cov.CovarianceHessianBFGS(1, sigma0_sq, d, dtype=torch.complex128, **kw)
+    return ref_cov.CovarianceHessianBFGSDCT(data_dir, sigma0_sq, d, dtype=torch.complex128,
+                                            use_precalculated_info=(kind == "dct_diagonal"), **kw)
+
+
+def gold_cov():
+    tmp = tempfile.mkdtemp()
+    dv_full = torch.load(os.path.join(REF, "data/imagenet/dct_variance.pt"), weights_only=True)
+    dv16 = dv_full[:, :16, :16].contiguous()
+    torch.save(dv16, os.path.join(tmp, "dct_variance.pt"))
+    cases = [
+        ("id_d5", "identity", (1, 5), {}, 4, None, False),
+        ("id_d15", "identity", (1, 15), {}, 6, 2, False),
+        ("id_d15_proj", "identity", (1, 15), {"project_to_diagonal": True}, 4, None, False),
+        ("id_d15_max0", "identity", (1, 15), {"max_vector_count": 0}, 3, None, False),
+        ("dct16", "dct_diagonal", (1, 3, 16, 16), {}, 6, 3, False),
+        ("dct16_noinfo", "dct_diagonal_noinfo", (1, 3, 16, 16), {}, 4, None, False),
+        ("dct16_onlycov", "dct_diagonal", (1, 3, 16, 16), {}, 4, None, True),
+    ]
+    out = {"dct_variance16": dv16}
+    for ci, (tag, kind, shape, kw, n, neg, onlycov) in enumerate(cases):
+        d = int(np.prod(shape[1:]))
+        sig0 = 80.0
+        cov = _mk_cov(kind, d, sig0 ** 2, shape, tmp, **kw)
+        steps = _script(1000 + ci, shape, n, sig0, neg)
+        probe = randn(shape, 2000 + ci)
+        out[f"{tag}__n"] = len(steps)
+        out[f"{tag}__meta"] = np.array(repr(dict(kind=kind, shape=shape, kw=kw, sigma0=sig0, only_cov=onlycov,
+                                                   n_steps=n, neg=neg, script_seed=1000 + ci, probe_seed=2000 + ci)))
+        for si, (what, a) in enumerate(steps):
+            pre = f"{tag}__{si}_"
+            if what == "time":
+                mean, score = cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"],
+                                                   **({"only_covariance": True} if onlycov else {}))
+                out.update({pre + "kind": 0, pre + "mean": mean, pre + "new_score": score})
+            else:
+                if onlycov:
+                    continue
+                cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+                out.update({pre + "kind": 1})
+            out[pre + "apply"] = cov.denoiser_cov_vector_dot(probe)
+            out[pre + "k"] = cov.vectors_denoiser_cov_u.shape[-1]
+            if d <= 15:
+                dm = cov.get_dense_matrices()
+                for nm, m in zip(("C", "Ci", "H", "Hi"), dm):
+                    out[pre + nm] = m
+    save("covariance", **out)
+
+
+# ------------------------------------------------------------------ 4. operators (a13)
+def _operator(name, size, sigma_s=0.1, seed=0):
+    kw = dict(name=name, device="cpu", sigma_s=sigma_s, kernel_size=61, intensity=1.0, scale_factor=4,
+              in_shape=(1, 3, size, size),
+              mask_opt={"mask_type": "random", "mask_len_range": (64, 156), "mask_prob_range": (0.6, 0.8),
+                        "image_size": size})
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return ref_meas.get_operator(**kw)
+
+
+def gold_ops():
+    out = {}
+    for size in (64, 256):
+        x = smooth_image(size, 5)
+        sub = (slice(None), slice(None), slice(None, None, size // 32), slice(None, None, size // 32))
+        for name in ("gaussian_blur", "motion_blur", "super_resolution", "inpainting"):
+            op = _operator(name, size, seed=3)
+            y = op.forward(x.clone(), noiseless=True)
+            yt = randn(y.shape, 77, torch.float32)
+            xt = op.transpose(yt.clone())
+            p = f"{name}_{size}_"
+            out[p + "y"] = y if size == 64 else y[sub] if name != "super_resolution" else y
+            out[p + "xt"] = xt if size == 64 else xt[sub]
+            out[p + "y_sum"] = y.double().sum()
+            out[p + "xt_sum"] = xt.double().sum()
+            out[p + "y_sq"] = (y.double() ** 2).sum()
+            out[p + "xt_sq"] = (xt.double() ** 2).sum()
+            if name == "inpainting":
+                out[p + "mask"] = op.mask[:, :1].to(torch.uint8)
+            if name in ("gaussian_blur", "motion_blur") and size == 64:
+                out[p + "FB"] = op.pre_calculated[0]
+    # bicubic Resizer matrix rows (SR measurement)
+    r = Resizer((1, 3, 256, 256), 1 / 4)
+    out["resizer_fov"] = r.field_of_view[0].squeeze()
+    out["resizer_w"] = r.weights[0].squeeze()
+    save("operators", **out)
+
+
+# ------------------------------------------------------------------ 5. solver calls (a11-a12)
+def gold_solver():
+    out = {}
+    size = 64
+    tmp = tempfile.mkdtemp()
+    dv_full = torch.load(os.path.join(REF, "data/imagenet/dct_variance.pt"), weights_only=True)
+    dv = dv_full[:, :size, :size].contiguous()
+    torch.save(dv, os.path.join(tmp, "dct_variance.pt"))
+    out["dct_variance64"] = dv
+    d = 3 * size * size
+    x = smooth_image(size, 9)
+    records = []
+    orig_cg = ref_cg.cg
+
+    def rec_cg(*a, **k):
+        sol, info = orig_cg(*a, **k)
+        records.append((info["niter"], bool(info["optimal"]), float(info["residual_norm"]), k.get("rtol")))
+        return sol, info
+
+    ref_cm.torch_cg.cg = rec_cg
+    for name in ("gaussian_blur", "motion_blur", "super_resolution", "inpainting"):
+        op = _operator(name, size, seed=4)
+        y = op.forward(x.clone(), noiseless=True)
+        y = y + 0.1 * randn(y.shape, 31, torch.float32)
+        if name == "inpainting":
+            y = y * op.mask
+        p = f"{name}_"
+        out[p + "y"] = y
+        if name == "inpainting":
+            out[p + "mask"] = op.mask[:, :1].to(torch.uint8)
+        cov = ref_cov.CovarianceHessianBFGSDCT(tmp, 80.0 ** 2, d, dtype=torch.complex128,
+                                               use_precalculated_info=True)
+        steps = _script(500, (1, 3, size, size), 3, 80.0)
+        sig_list = [s[1]["sigma_next"] if s[0] == "time" else s[1]["sigma"] for s in steps]
+        for si, (what, a) in enumerate(steps):
+            if what == "time":
+                cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+            else:
+                cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+            x0_mean = (x + 0.05 * randn(x.shape, 600 + si, torch.float32)).to(F64)
+            for sigma_t in (sig_list[si], 0.05):
+                records.clear()
+                mat = ref_cm.choose_solver(name, op, y, x0_mean, None, cov, "customcuda", 1.0, sigma_t=sigma_t)
+                q = f"{p}{si}_{'lo' if sigma_t == 0.05 else 'hi'}_"
+                out[q + "sigma_t"] = sigma_t
+                out[q + "mat_sub"] = mat[..., ::2, ::2]  # strided sample + moments pin the full field
+                out[q + "mat_sum"] = mat.double().sum()
+                out[q + "mat_sq"] = (mat.double() ** 2).sum()
+                out[q + "niter"] = records[0][0]
+                out[q + "optimal"] = records[0][1]
+                out[q + "resnorm"] = records[0][2]
+                out[q + "rtol"] = records[0][3]
+    out["script_seed"] = 500
+    ref_cm.torch_cg.cg = orig_cg
+    save("solver", **out)
+
+
+# ------------------------------------------------------------------ 6. whole trajectories (a1, a6)
+def gold_traj():
+    size = 64
+    tmp = tempfile.mkdtemp() + "/"
+    dv_full = torch.load(os.path.join(REF, "data/imagenet/dct_variance.pt"), weights_only=True)
+    torch.save(dv_full[:, :size, :size].contiguous(), os.path.join(tmp, "dct_variance.pt"))
+    net = ref_net(SMALL_A, 11)
+    base = dict(conditioning_mechanism="online_covariance", cond_scaling=1.0, clip_x0_mean=False,
+                pigdm_posthoc_scaling=False, max_vector_count=100000, dataset_path=tmp,
+                image_base_covariance="dct_diagonal", pca_component_count=10,
+                denoiser_mean_error_threshold=0.2, use_analytical_score_time_update=True,
+                project_to_diagonal=False, space_step_update_threshold=10.0,
+                space_step_update_lower_threshold=1.0, max_rtol=1.0, do_space_updates=True,
+                use_analytic_var_at_end=False, solver_type="customcuda", use_rtol_func=False, diffpir_lambda=10.0)
+    cases = [
+        ("gb_heun10", "gaussian_blur", "heun", 10, {}),
+        ("mb_heun10", "motion_blur", "heun", 10, {}),
+        ("sr_heun10", "super_resolution", "heun", 10, {}),
+        ("ip_euler20", "inpainting", "euler", 20, {}),
+        ("gb_heun10_nospace", "gaussian_blur", "heun", 10, {"do_space_updates": False}),
+        ("gb_heun10_readme", "gaussian_blur", "heun", 10, {"space_step_update_lower_threshold": 1000.0,
+                                                           "space_step_update_threshold": 5.0}),
+        ("gb_heun10_identity", "gaussian_blur", "heun", 10, {"image_base_covariance": "identity"}),
+        ("gb_heun30", "gaussian_blur", "heun", 30, {}),
+    ]
+    trace, holder = [], {}
+    orig_cg, orig_get_op, orig_choose = ref_cg.cg, ref_gc.get_operator, ref_gc.choose_conditioning_mechanism
+
+    def rec_cg(*a, **k):
+        sol, info = orig_cg(*a, **k)
+        trace.append({"niter": info["niter"]})
+        return sol, info
+
+    def rec_get_op(**kw):
+        holder["op"] = orig_get_op(**kw)
+        return holder["op"]
+
+    class Recorder(ref_cm.BFGSOnlineUpdate):
+        def x0_mean_update(self, x_t, model, y, sigma):
+            calls = {"n": 0}
+            cm = self.covariance_model
+            orig_dot = cm.denoiser_cov_vector_dot
+
+            def counting(v, use_cuda=False):
+                calls["n"] += 1
+                return orig_dot(v, use_cuda)
+
+            cm.denoiser_cov_vector_dot = counting
+            n_before = len(trace)
+            out = super().x0_mean_update(x_t, model, y, sigma)
+            cm.denoiser_cov_vector_dot = orig_dot
+            rec = trace[n_before]
+            # CG calls the dot niter+1 times (initial residual + one per iteration); one more = the cov branch
+            rec["branch_cov"] = int(calls["n"] > rec["niter"] + 1)
+            rec["k"] = cm.vectors_denoiser_cov_u.shape[-1]
+            rec["sigma"] = float(sigma)
+            rec["out_sum"] = float(out.detach().double().sum())
+            return out
+
+    ref_cm.torch_cg.cg = rec_cg
+    ref_gc.get_operator = rec_get_op
+    ref_gc.choose_conditioning_mechanism = lambda name: Recorder
+    out = {"cfg": cfg_dict(SMALL_A), "unet_seed": 11,
+           "dct_variance64": dv_full[:, :size, :size].contiguous()}
+    for ci, (tag, opname, solver, nsteps, over) in enumerate(cases):
+        x0 = smooth_image(size, 40 + ci)
+        noise = randn((1, 3, size, size), 50 + ci, torch.float32)
+        op_kw = dict(name=opname, device=torch.device("cpu"), sigma_s=0.1, kernel_size=61, intensity=1.0,
+                     scale_factor=4, in_shape=(1, 3, size, size),
+                     mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
+                               "mask_prob_range": (0.6, 0.8), "image_size": size})
+        trace.clear()
+        np.random.seed(60 + ci)
+        torch.manual_seed(60 + ci)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            x_final, _x_all, y = ref_gc.conditional_sampler(
+                net, noise, x0.clone(), op_kw, {}, num_steps=nsteps, sigma_min=0.002, sigma_max=80, rho=7,
+                solver=solver, **{**base, **over})
+        p = tag + "__"
+        out.update({p + "seeds": np.array([40 + ci, 50 + ci]), p + "y": y, p + "x_final": x_final,
+                    p + "op": np.array(opname), p + "solver": np.array(solver), p + "num_steps": nsteps,
+                    p + "over": np.array(repr(over)),
+                    p + "niter": np.array([t["niter"] for t in trace]),
+                    p + "branch_cov": np.array([t["branch_cov"] for t in trace]),
+                    p + "k": np.array([t["k"] for t in trace]),
+                    p + "sigma": np.array([t["sigma"] for t in trace]),
+                    p + "out_sum": np.array([t["out_sum"] for t in trace])})
+        if opname == "inpainting":
+            out[p + "mask"] = holder["op"].mask[:, :1].to(torch.uint8)
+        print(tag, "calls", len(trace), "niter sum", int(np.sum(out[p + "niter"])), "k", out[p + "k"][-1],
+              "cov-branch", int(np.sum(out[p + "branch_cov"])))
+    ref_cm.torch_cg.cg, ref_gc.get_operator, ref_gc.choose_conditioning_mechanism = orig_cg, orig_get_op, orig_choose
+    save("trajectories", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sigma", "unet", "cov", "ops", "solver", "traj"]
+    torch.set_num_threads(8)
+    for w in which:
+        {"sigma": gold_sigma, "unet": gold_unet, "cov": gold_cov, "ops": gold_ops, "solver": gold_solver,
+         "traj": gold_traj}[w]()

@@ -1,0 +1,237 @@
+"""The oracle (CPU restatement) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  No GPU, no reference import."""
+import numpy as np
+import pytest
+import torch
+
+import inputs
+from oracle import fh_oracle as fo
+from oracle import unet_oracle as uo
+
+F64 = torch.float64
+DATA = None
+
+
+def T(a):
+    if isinstance(a, torch.Tensor):
+        return a.detach()
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxabs(a, b):
+    return float((T(a).double() - T(b).double()).abs().max())
+
+
+# ---------------------------------------------------------------- a2
+@pytest.mark.parametrize("n", [10, 30, 100])
+def test_sigma_grid(gold, n):
+    g = gold("sigma_grids")
+    u = fo.linear_sigma_table()
+    assert np.array_equal(u.numpy(), g["u"])
+    t = fo.edm_sigma_steps(u, n)
+    assert np.array_equal(t.numpy(), g[f"t_{n}"])
+    assert np.array_equal(fo.round_sigma_index(u, T(g[f"raw_{n}"])).numpy(), g[f"idx_{n}"].reshape(-1))
+
+
+# ---------------------------------------------------------------- a3-a5
+@pytest.mark.parametrize("tag,cfg", [("unet_a", inputs.SMALL_A), ("unet_b", inputs.SMALL_B)])
+def test_unet_precond_vjp(gold, tag, cfg):
+    g = gold(tag)
+    seed = int(g["seed"])
+    sd = uo.seeded_state(cfg, seed)
+    model = uo.OracleUNet(cfg, sd)
+    net = fo.LinearPrecond(model)
+    x = inputs.randn((1, 3, 64, 64), seed + 100) * 3.0
+    for j in range(3):
+        sigma = torch.tensor(float(g[f"sigma_{j}"]), dtype=F64)
+        with torch.no_grad():
+            c_in = 1 / (sigma ** 2 + 1).sqrt()
+            raw = model(c_in.float() * x.float(), T(g[f"tstep_{j}"]).long().flatten())
+        assert maxabs(raw, g[f"raw_{j}"]) < 2e-4 * max(1.0, float(np.abs(g[f"raw_{j}"]).max()))
+        xt = x.clone().requires_grad_()
+        if cfg.learn_sigma:
+            D, var = net(xt, sigma)
+            assert maxabs(var, g[f"x0_var_{j}"]) <= 1e-3 * float(np.abs(g[f"x0_var_{j}"]).max())
+        else:
+            D = xt.float() - sigma.float() * model(c_in.float() * xt.float(), T(g[f"tstep_{j}"]).long().flatten())
+        assert D.dtype == T(g[f"D_{j}"]).dtype
+        assert maxabs(D, g[f"D_{j}"]) < 1e-3
+        cot = inputs.randn(D.shape, seed + 200 + j).to(D.dtype)
+        (vjp,) = torch.autograd.grad((cot * D).sum(), xt)
+        ref = T(g[f"vjp_{j}"])
+        assert maxabs(vjp, ref) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+# ---------------------------------------------------------------- a7-a10
+def _cov_cases(g):
+    return sorted({k.split("__")[0] for k in g.files if "__meta" in k})
+
+
+def test_covariance_sequences(gold, tmp_path):
+    g = gold("covariance")
+    torch.save(T(g["dct_variance16"]), tmp_path / "dct_variance.pt")
+    for tag in _cov_cases(g):
+        meta = eval(str(g[f"{tag}__meta"]))
+        shape = meta["shape"]
+        d = int(np.prod(shape[1:]))
+        cov = fo.make_covariance(meta["kind"], str(tmp_path), meta["sigma0"] ** 2, d,
+                                 max_vector_count=meta["kw"].get("max_vector_count"),
+                                 project_to_diagonal=meta["kw"].get("project_to_diagonal", False))
+        steps = inputs.script(meta["script_seed"], shape, meta["n_steps"], meta["sigma0"], meta["neg"])
+        probe = inputs.randn(shape, meta["probe_seed"])
+        for si, (what, a) in enumerate(steps):
+            pre = f"{tag}__{si}_"
+            if what == "time":
+                mean, score = cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"],
+                                                   only_covariance=meta["only_cov"])
+                sc = max(1.0, float(np.abs(g[pre + "mean"]).max()))
+                assert maxabs(mean, g[pre + "mean"]) < 1e-9 * sc, (tag, si)
+                assert maxabs(score, g[pre + "new_score"]) < 1e-9 * sc, (tag, si)
+            else:
+                if meta["only_cov"]:
+                    continue
+                cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+            assert cov.k == int(g[pre + "k"])
+            ref = g[pre + "apply"]
+            assert maxabs(cov.denoiser_cov_vector_dot(probe), ref) < 1e-9 * max(1.0, float(np.abs(ref).max())), (tag, si)
+            if d <= 15:
+                for nm, m in zip(("C", "Ci", "H", "Hi"), cov.dense()):
+                    r = T(g[pre + nm])
+                    assert float((m - r).abs().max()) < 1e-8 * max(1.0, float(r.abs().max())), (tag, si, nm)
+
+
+def test_covariance_vs_dense_helpers():
+    """Known-answer: the dense update rules (online_update_bfgs.py:377-463) against the low-rank object."""
+    d, s0 = 6, 5.0
+    cov = fo.OracleCovariance(1.0, s0 ** 2, d)
+    C, Ci, H, Hi = (m.real.clone() for m in cov.dense())
+    g = inputs.rng(3)
+    x = torch.randn(1, d, generator=g, dtype=F64)
+    score = torch.randn(1, d, generator=g, dtype=F64)
+    sig = [5.0, 3.0, 2.0, 1.2]
+    for i in range(3):
+        mean, nsc = cov.update_time_step(x, sig[i], sig[i + 1], score)
+        C, Ci, H, Hi, dsc, dmean = fo.dense_time_update(x[0], C, Ci, H, Hi, score[0], sig[i], sig[i + 1])
+        assert maxabs(mean[0], dmean) < 1e-6 and maxabs(nsc[0], dsc) < 1e-6
+        xn = x + 0.3 * torch.randn(1, d, generator=g, dtype=F64)
+        m1 = mean + 0.4 * (xn - x) + 0.02 * torch.randn(1, d, generator=g, dtype=F64)
+        cov.update_space_step(mean, m1, sig[i + 1], x, xn)
+        C, Ci, H, Hi = fo.dense_space_update(C, Ci, mean[0], m1[0], sig[i + 1], (xn - x)[0])
+        for a, b in zip(cov.dense(), (C, Ci, H, Hi)):
+            assert float((a.real - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+        x, score = xn, (m1 - xn) / sig[i + 1] ** 2
+
+
+# ---------------------------------------------------------------- a13
+def _mk_op(name, size, g=None, prefix=None, sigma_s=0.1):
+    import os
+    import scipy.io
+    kd = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "free-hunch_amd", "data", "kernels")
+    if name == "gaussian_blur":
+        return fo.OracleOperator(name, (1, 3, size, size), sigma_s, kernel=np.load(os.path.join(kd, "gaussian_ks61_std3.0.npy")))
+    if name == "motion_blur":
+        return fo.OracleOperator(name, (1, 3, size, size), sigma_s, kernel=np.load(os.path.join(kd, "motion_ks61_std0.5.npy")))
+    if name == "super_resolution":
+        k = scipy.io.loadmat(os.path.join(kd, "kernels_bicubicx234.mat"))["kernels"][0, 2].astype(np.float64)
+        return fo.OracleOperator(name, (1, 3, size, size), sigma_s, kernel=k, scale_factor=4)
+    mask = T(g[prefix + "mask"]).float().repeat(1, 3, 1, 1)
+    return fo.OracleOperator(name, (1, 3, size, size), sigma_s, mask=mask)
+
+
+@pytest.mark.parametrize("size", [64, 256])
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
+def test_operators(gold, name, size):
+    g = gold("operators")
+    p = f"{name}_{size}_"
+    op = _mk_op(name, size, g, p)
+    x = inputs.smooth_image(size, 5)
+    y = op.forward(x.clone())
+    yt = inputs.randn(y.shape, 77, torch.float32)
+    xt = op.transpose(yt.clone())
+    st = size // 32
+    ysub = y if (size == 64 or name == "super_resolution") else y[..., ::st, ::st]
+    xsub = xt if size == 64 else xt[..., ::st, ::st]
+    assert maxabs(ysub, g[p + "y"]) < 2e-6
+    assert maxabs(xsub, g[p + "xt"]) < 2e-5
+    assert abs(float(y.double().sum()) - float(g[p + "y_sum"])) < 1e-3
+    assert abs(float((y.double() ** 2).sum()) - float(g[p + "y_sq"])) < 1e-3 * max(1.0, float(g[p + "y_sq"]))
+    assert abs(float((xt.double() ** 2).sum()) - float(g[p + "xt_sq"])) < 1e-4 * max(1.0, float(g[p + "xt_sq"]))
+
+
+def test_resizer_matrix(gold):
+    g = gold("operators")
+    _, fov, w = fo.bicubic_matrix(256, 0.25)
+    assert np.array_equal(fov.T, g["resizer_fov"])
+    assert np.allclose(w.T, g["resizer_w"], rtol=0, atol=1e-7)
+
+
+# ---------------------------------------------------------------- a11-a12
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
+def test_solver_calls(gold, name, tmp_path):
+    g = gold("solver")
+    size = 64
+    torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
+    p = f"{name}_"
+    op = _mk_op(name, size, g, p)
+    x = inputs.smooth_image(size, 9)
+    op.forward(x.clone())  # caches pre_calculated
+    y = T(g[p + "y"])
+    cov = fo.make_covariance("dct_diagonal", str(tmp_path), 80.0 ** 2, 3 * size * size)
+    steps = inputs.script(int(g["script_seed"]), (1, 3, size, size), 3, 80.0)
+    for si, (what, a) in enumerate(steps):
+        if what == "time":
+            cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+        else:
+            cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+        x0_mean = (x + 0.05 * inputs.randn(x.shape, 600 + si, torch.float32)).to(F64)
+        for lab in ("hi", "lo"):
+            q = f"{p}{si}_{lab}_"
+            info = []
+            mat = fo.solve_mat(op, y, x0_mean, cov, 1.0, float(g[q + "sigma_t"]), info)
+            assert info[0]["niter"] == int(g[q + "niter"]), (q, info[0])
+            assert info[0]["optimal"] == bool(g[q + "optimal"])
+            ref = T(g[q + "mat_sub"])
+            assert maxabs(mat[..., ::2, ::2], ref) < 1e-6 * max(1.0, float(ref.abs().max())), q
+            assert abs(float((mat.double() ** 2).sum()) - float(g[q + "mat_sq"])) < 1e-6 * float(g[q + "mat_sq"])
+
+
+# ---------------------------------------------------------------- a1, a6
+def _traj_cases(g):
+    return sorted({k.split("__")[0] for k in g.files if "__" in k})
+
+
+def run_oracle_traj(g, tag, tmp_path):
+    p = tag + "__"
+    over = eval(str(g[p + "over"]))
+    opname, solver, nsteps = str(g[p + "op"]), str(g[p + "solver"]), int(g[p + "num_steps"])
+    s_img, s_noise = (int(v) for v in g[p + "seeds"])
+    size = 64
+    cfg = inputs.SMALL_A
+    net = fo.LinearPrecond(uo.OracleUNet(cfg, uo.seeded_state(cfg, int(g["unet_seed"]))))
+    op = _mk_op(opname, size, g, p)
+    x0 = inputs.smooth_image(size, s_img)
+    if opname != "inpainting":
+        op.forward(x0.clone())
+    noise = inputs.randn((1, 3, size, size), s_noise, torch.float32)
+    y = T(g[p + "y"])
+    kw = dict(image_base_covariance=over.get("image_base_covariance", "dct_diagonal"), data_dir=str(tmp_path),
+              do_space_updates=over.get("do_space_updates", True),
+              space_step_update_threshold=over.get("space_step_update_threshold", 10.0),
+              space_step_update_lower_threshold=over.get("space_step_update_lower_threshold", 1.0))
+    fac = lambda op_, v0, d: fo.OracleFreeHunch(1.0, op_, False, v0, d, **kw)
+    return fo.conditional_sampler(net, noise, y, op, num_steps=nsteps, solver=solver, mechanism_factory=fac)
+
+
+@pytest.mark.parametrize("tag", ["gb_heun10", "mb_heun10", "sr_heun10", "ip_euler20", "gb_heun10_nospace",
+                                 "gb_heun10_readme", "gb_heun10_identity"])
+def test_trajectory(gold, tag, tmp_path):
+    g = gold("trajectories")
+    torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
+    x, mech = run_oracle_traj(g, tag, tmp_path)
+    p = tag + "__"
+    tr = mech.trace
+    assert [t["k"] for t in tr] == list(g[p + "k"])
+    assert [int(t["branch"] == "cov") for t in tr] == list(g[p + "branch_cov"])
+    assert [t["niter"] for t in tr] == list(g[p + "niter"])
+    assert np.allclose([t["sigma"] for t in tr], g[p + "sigma"], rtol=0, atol=0)
+    assert maxabs(x, g[p + "x_final"]) < 1e-3
