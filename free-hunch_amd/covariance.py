@@ -1,0 +1,293 @@
+"""Device-resident Free Hunch covariance state: the reference's ``CovarianceHessianBFGS`` /
+``CovarianceHessianBFGSDCT`` (conditioning_utils/online_update_bfgs.py:7-374) re-designed for HBM.
+
+Reference layout: four matrices (denoiser covariance C, C^-1, Hessian H, H^-1), each kept as
+``diag + U U^T - V V^T`` with complex128 U, V (plain transposes), rebuilt on the CPU by two Woodbury
+steps with ``scipy.linalg.sqrtm`` and re-uploaded after every update (8 factor matrices, 16 B/entry).
+
+Here every representation is real:   X = diag(D) + diag(r) B M B^T diag(r)
+  * B  [m_cap][d] float64, column-major, one *shared* base per family: C and C^-1 share ``Bc``,
+    H and H^-1 share ``Bh``.  Columns are the raw BFGS pairs (de, C dx); they are written once and never
+    rewritten - a Woodbury inverse only rescales rows (``r <- r / D``) and replaces the small matrix
+    ``M <- -M (I + G M)^-1`` with ``G = B^T diag(r^2 / D) B``.
+  * D, r [d] float64 per representation, M [m][m] float64 per representation (host master, device copy).
+The complex square roots of the reference disappear: ``U U^T - V V^T`` is always real, only its
+factorisation was complex.  2 bases instead of 8 factor matrices, 8 B/entry instead of 16 B, and no
+factor ever crosses PCIe.  All d-sized work runs in libfh_hip.so (fh_rep_apply / fh_rep_invert /
+fh_space_*); the m x m algebra (m <= 2 * number of space updates) stays on the host in float64.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+
+class _Rep:
+    """One representation over a shared base: diagonal D, row scale r, inner matrix M."""
+
+    def __init__(self, D, m_cap):
+        self.D = D
+        self.r = torch.ones_like(D)
+        self.M = np.zeros((0, 0))
+        self.M_dev = torch.zeros(m_cap, m_cap, dtype=F64, device=D.device)
+
+    def set_M(self, M):
+        self.M = M
+        m = M.shape[0]
+        if m:
+            self.M_dev[:m, :m].copy_(torch.from_numpy(np.ascontiguousarray(M)))
+
+    def grow(self, m_cap):
+        new = torch.zeros(m_cap, m_cap, dtype=F64, device=self.D.device)
+        m = self.M.shape[0]
+        if m:
+            new[:m, :m].copy_(self.M_dev[:m, :m])
+        self.M_dev = new
+
+
+class _Family:
+    def __init__(self, d, m_cap, device):
+        self.B = torch.empty(m_cap, d, dtype=F64, device=device)
+        self.m = 0
+
+    def grow(self, m_cap):
+        new = torch.empty(m_cap, self.B.shape[1], dtype=F64, device=self.B.device)
+        if self.m:
+            new[: self.m].copy_(self.B[: self.m])
+        self.B = new
+
+
+def _woodbury_inner(M, G):
+    """M_inv = -M (I + G M)^-1, symmetrised (the m x m part of online_update_bfgs.py:87-119)."""
+    m = M.shape[0]
+    if m == 0:
+        return M
+    out = -M @ np.linalg.inv(np.eye(m) + G @ M)
+    return 0.5 * (out + out.T)
+
+
+class CovarianceHessianBFGS:
+    """Same public surface as the reference class (online_update_bfgs.py:7-336); `device` is new.
+
+    `init_denoiser_variance` is a scalar or a [data_dim] tensor; `init_noise_variance` a float (sigma_0^2).
+    Vectors passed to the update methods have shape (1, 3, S, S) (batch 1, as the reference asserts)."""
+
+    use_dct = False
+
+    def __init__(self, init_denoiser_variance, init_noise_variance, data_dim, dtype=None, max_vector_count=None,
+                 init_denoiser_cov_u=None, project_to_diagonal=False, use_precalculated_info=True, device=None,
+                 m_cap=64):
+        assert init_denoiser_cov_u is None, "a non-empty initial factor is not supported"
+        self.device = torch.device(device if device is not None else "cuda")
+        S = int(round(math.sqrt(data_dim / 3)))
+        if 3 * S * S != data_dim:
+            raise ValueError(f"data_dim={data_dim} is not 3*S*S")
+        self.S, self.data_dim = S, data_dim
+        self.max_vector_count = max_vector_count
+        self.project_to_diagonal = project_to_diagonal
+        self.ctx = _lib.Context.get(S, 3, _lib_max_cols())
+        self.m_cap = m_cap
+        d = data_dim
+        var = torch.as_tensor(init_denoiser_variance, dtype=F64).reshape(-1).to(self.device)
+        Dc = (torch.ones(d, dtype=F64, device=self.device) * var).contiguous()
+        self.famC, self.famH = _Family(d, m_cap, self.device), _Family(d, m_cap, self.device)
+        self.C, self.Ci = _Rep(Dc, m_cap), _Rep(torch.empty_like(Dc), m_cap)
+        self.H, self.Hi = _Rep(torch.empty_like(Dc), m_cap), _Rep(torch.empty_like(Dc), m_cap)
+        self._G = torch.zeros(m_cap, m_cap, dtype=F64, device=self.device)
+        self._scal = torch.zeros(8, dtype=F64, device=self.device)
+        self._t0, self._t1, self._t2 = (torch.empty(d, dtype=F64, device=self.device) for _ in range(3))
+        self._derive_from_cov(np.sqrt(init_noise_variance))
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def k(self):
+        """number of stored (u, v) pairs of the covariance (reference: vectors_denoiser_cov_u.shape[-1])"""
+        return self.famC.m // 2
+
+    def _ensure_capacity(self, need):
+        if need <= self.m_cap:
+            return
+        cap = self.m_cap
+        while cap < need:
+            cap *= 2
+        if cap > _lib_max_cols():
+            raise _lib.FhError(f"more than {_lib_max_cols()} factor columns requested")
+        for fam in (self.famC, self.famH):
+            fam.grow(cap)
+        for rep in (self.C, self.Ci, self.H, self.Hi):
+            rep.grow(cap)
+        self._G = torch.zeros(cap, cap, dtype=F64, device=self.device)
+        self.m_cap = cap
+
+    def _invert(self, src, dst, fam, shift=0.0):
+        """dst <- (src + shift*I)^-1 over the family's base; src.D is shifted in place."""
+        m = fam.m
+        self.ctx.rep_invert(src.D, src.r, fam.B, shift, dst.D, dst.r, self._G, m)
+        if m:
+            G = self._G[:m, :m].cpu().numpy()
+            dst.set_M(_woodbury_inner(src.M, G))
+        else:
+            dst.set_M(np.zeros((0, 0)))
+
+    def _apply(self, rep, fam, z, out):
+        return self.ctx.rep_apply(rep.D, rep.r, fam.B, rep.M_dev, z, out, fam.m)
+
+    def _derive_from_cov(self, sigma):
+        """set_others_corresponding_to_current_denoiser_cov (:327-330) for an EMPTY factor."""
+        assert self.famC.m == 0
+        s2 = float(sigma) ** 2
+        self.famH.m = 0
+        for rep in (self.C, self.Ci, self.H, self.Hi):
+            rep.r.fill_(1.0)
+            rep.set_M(np.zeros((0, 0)))
+        self._invert(self.C, self.Ci, self.famC)
+        torch.div(self.C.D, s2, out=self.H.D)
+        self.H.D.sub_(1.0).div_(s2)
+        self._invert(self.H, self.Hi, self.famH)
+
+    def _vec(self, x):
+        return x.detach().to(device=self.device, dtype=F64).reshape(-1).contiguous()
+
+    def transform(self, x):
+        return x
+
+    def inverse_transform(self, x):
+        return x
+
+    def _fwd(self, v, out=None):
+        return v
+
+    def _bwd(self, v, out=None):
+        return v
+
+    # ------------------------------------------------------------------ :194-204
+    def denoiser_cov_vector_dot(self, v, use_cuda=True):
+        shape, dtype = v.shape, v.dtype
+        z = self._fwd(self._vec(v))
+        out = self._apply(self.C, self.famC, z, torch.empty_like(z))
+        return self._bwd(out).reshape(shape).to(dtype)
+
+    # ------------------------------------------------------------------ :153-192
+    def update_time_step(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance=False):
+        shape = x_t.shape
+        assert shape[0] == 1, "Batch size must be 1"
+        sigma_t, sigma_tnext = float(sigma_t), float(sigma_tnext)
+        # the reference multiplies the increment by a float32 `torch.ones` (:166, :172): float32-rounded scalars
+        self._invert(self.Ci, self.C, self.famC, shift=float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2))))
+        if only_covariance:
+            x = x_t.detach().to(device=self.device, dtype=F64)
+            return x.clone(), x.clone()
+        x = self._fwd(self._vec(x_t))
+        s = self._fwd(self._vec(score_t))
+        t = self._apply(self.Hi, self.famH, s, self._t0)  # old H^-1 score, before the diagonal moves
+        self._invert(self.Hi, self.H, self.famH, shift=-float(np.float32(sigma_tnext ** 2 - sigma_t ** 2)))
+        new_score = self._apply(self.H, self.famH, t, torch.empty_like(t))
+        new_mean = self.ctx.axpby(1.0, x, sigma_tnext ** 2, new_score, torch.empty_like(x))
+        return self._bwd(new_mean).reshape(shape), self._bwd(new_score).reshape(shape)
+
+    # ------------------------------------------------------------------ :250-312
+    def update_space_step(self, denoiser_mean_at_x, denoiser_mean_at_xnext, sigma_t, x, xnext):
+        assert x.shape[0] == 1, "Batch size must be 1"
+        ctx, lib = self.ctx, self.ctx.lib
+        sigma_t = float(sigma_t)
+        s2 = sigma_t ** 2
+        d = self.data_dim
+        dx = self._fwd(ctx.axpby(1.0, self._vec(xnext), -1.0, self._vec(x), self._t0))
+        dm = self._fwd(ctx.axpby(1.0, self._vec(denoiser_mean_at_xnext), -1.0, self._vec(denoiser_mean_at_x),
+                                 self._t1))
+        if dx.data_ptr() == self._t0.data_ptr():  # identity basis: _fwd returned the scratch itself
+            dx, dm = dx.clone(), dm.clone()
+        de = self._t1
+        st = _lib.stream()
+        _lib.check(lib.fh_space_prep(ctx.h, _lib.ptr(dm), s2, _lib.ptr(dx), _lib.ptr(de), _lib.ptr(self._scal), d, st),
+                   "fh_space_prep")
+        cdx = self._apply(self.C, self.famC, dx, self._t2)
+        _lib.check(lib.fh_dot(ctx.h, _lib.ptr(cdx), _lib.ptr(dx), _lib.ptr(self._scal), 1, d, st), "fh_dot")
+        dx_de, q = ctx.read_scalars(self._scal, 2)
+        gamma = 1.0 / dx_de
+        project = bool(self.project_to_diagonal)
+        mc, mh = self.famC.m, self.famH.m
+        self._ensure_capacity(max(mc if project else mc + 2, mh + 2))
+        Bc, Bh = self.famC.B, self.famH.B
+        _lib.check(lib.fh_space_commit(
+            ctx.h, _lib.ptr(de), _lib.ptr(cdx), gamma, q, s2, _lib.ptr(self.C.D), _lib.ptr(self.C.r),
+            None if project else Bc[mc].data_ptr(), None if project else Bc[mc + 1].data_ptr(),
+            _lib.ptr(self.H.D), _lib.ptr(self.H.r), Bh[mh].data_ptr(), Bh[mh + 1].data_ptr(), int(project), d, st),
+            "fh_space_commit")
+        if not project:
+            self.famC.m = mc + 2
+            self.C.set_M(_blockdiag(self.C.M, gamma, -1.0 / q))
+        self.famH.m = mh + 2
+        self.H.set_M(_blockdiag(self.H.M, gamma / s2 ** 2, -1.0 / (q * s2 ** 2)))
+        self._invert(self.C, self.Ci, self.famC)
+        self._invert(self.H, self.Hi, self.famH)
+        if self.max_vector_count is not None:
+            self.drop_vectors(self.max_vector_count, sigma_t)
+
+    # ------------------------------------------------------------------ :233-245
+    def drop_vectors(self, max_vector_count, sigma):
+        if max_vector_count == 0:
+            self.famC.m = 0
+            self._derive_from_cov(sigma)
+        elif self.k > max_vector_count:
+            raise NotImplementedError(
+                "0 < max_vector_count < k drops columns of the reference's sqrtm-mixed complex factors "
+                "(online_update_bfgs.py:240-244); that factorisation is not kept on the device")
+
+    # ------------------------------------------------------------------ :320-325 (small d, tests only)
+    def get_dense_matrices(self):
+        out = []
+        for rep, fam in ((self.C, self.famC), (self.Ci, self.famC), (self.H, self.famH), (self.Hi, self.famH)):
+            W = (fam.B[: fam.m] * rep.r[None, :]).T
+            M = torch.from_numpy(np.ascontiguousarray(rep.M)).to(self.device)
+            out.append(torch.diag(rep.D) + W @ M @ W.T)
+        return tuple(out)
+
+
+def _blockdiag(M, a, b):
+    m = M.shape[0]
+    out = np.zeros((m + 2, m + 2))
+    out[:m, :m] = M
+    out[m, m], out[m + 1, m + 1] = a, b
+    return out
+
+
+def _lib_max_cols():
+    return 256
+
+
+class CovarianceHessianBFGSDCT(CovarianceHessianBFGS):
+    """All operations in the orthonormal 2-D DCT basis (online_update_bfgs.py:339-374); the prior diagonal is
+    ``<data_dir>/dct_variance.pt`` when `use_precalculated_info`, else ones."""
+
+    use_dct = True
+
+    def __init__(self, data_dir, init_noise_variance, data_dim, dtype=None, max_vector_count=None, **kwargs):
+        use_info = kwargs.pop("use_precalculated_info")
+        if use_info:
+            var = torch.load(os.path.join(data_dir, "dct_variance.pt"), weights_only=True).reshape(-1)
+            if var.numel() != data_dim:
+                raise ValueError(f"dct_variance.pt has {var.numel()} entries, data_dim is {data_dim}")
+        else:
+            var = torch.ones(data_dim)
+        self.dct_variance = var
+        super().__init__(var, init_noise_variance, data_dim, dtype, max_vector_count, **kwargs)
+
+    def transform(self, x):
+        return self.ctx.dct2d(x.detach().to(device=self.device, dtype=F64).contiguous()).to(x.dtype)
+
+    def inverse_transform(self, x):
+        return self.ctx.dct2d(x.detach().to(device=self.device, dtype=F64).contiguous(), inverse=True).to(x.dtype)
+
+    def _fwd(self, v, out=None):
+        return self.ctx.dct2d(v.view(3, self.S, self.S)).view(-1)
+
+    def _bwd(self, v, out=None):
+        return self.ctx.dct2d(v.view(3, self.S, self.S), inverse=True).view(-1)

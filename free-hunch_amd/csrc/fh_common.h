@@ -1,0 +1,55 @@
+// Shared device helpers for the Free Hunch gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fh_hip.h"
+
+#define FH_CHECK(expr)                       \
+  do {                                       \
+    hipError_t e_ = (expr);                  \
+    if (e_ != hipSuccess) return (int)e_;    \
+  } while (0)
+#define FH_LAUNCH_CHECK() FH_CHECK(hipGetLastError())
+
+namespace fh {
+
+constexpr int kWave = 64;
+constexpr int kPartialRows = 1024;  // max workgroups that write reduction partials
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
+  return v;
+}
+
+// Sum over a 256-thread block; result valid in every thread.  `red` holds >= 4 doubles.
+__device__ __forceinline__ double block_sum_256(double v, double* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace fh
+
+struct fh_cg_state {  // device-resident control block of the CG loop
+  double rz, pAp, rnorm, stop, bnorm;
+  int done, niter, optimal, pad;
+};
+
+struct fh_context {
+  int S, planes_max, m_cap;
+  double* basis;      // [S][S]  C[k][n] = s_k cos(pi (2n+1) k / 2S)
+  double* basis_t;    // [S][S]  transpose
+  double* tmp_img;    // [planes_max*S*S] DCT intermediate
+  double* partial;    // [kPartialRows][FH_MAX_COLS] block partials (dots) / scalar partials
+  double* gpartial;   // Gram partials
+  int64_t gpartial_elems;
+  double* coef;       // [2*FH_MAX_COLS] t and M t
+  // CG work vectors (n <= planes_max*S*S)
+  double *cg_r, *cg_p, *cg_ap, *w0, *w1, *w2;
+  fh_cg_state* cg_state;
+};

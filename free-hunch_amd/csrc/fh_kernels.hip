@@ -1,0 +1,874 @@
+// Free Hunch covariance / DCT / operator / CG kernels for gfx950 (CDNA4, wave64), float64.
+//
+// Everything on this side of the path is HBM- or latency-bound vector work on d = 3*S*S elements
+// plus the d x m factor base; the kernels are organised around coalesced 16-byte row-pair accesses,
+// wave shuffles + LDS for reductions, and deterministic two-stage sums (no float atomics, so a solve
+// is bitwise reproducible).  Every kernel that runs inside the CG loop takes a device `done` flag and
+// returns at once when it is set, which lets the host enqueue iterations in chunks without changing
+// the reference's stopping rule.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fh_common.h"
+
+using namespace fh;
+
+#define DONE_GUARD(done) \
+  if ((done) != nullptr && *(done) != 0) return
+
+// ------------------------------------------------------------------------------------------------
+// Small float64 GEMM used by the DCT passes:  C = A * op(B),  A [M][K] (lda), C [M][N] (ldc),
+// BT ? B [N][K] : B [K][N]  (ldb).  32x32 tile, BK = 16, 2x2 outputs per thread.
+// ------------------------------------------------------------------------------------------------
+template <bool BT>
+__global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
+                                                  double* __restrict__ C, int M, int N, int K, int lda, int ldb,
+                                                  int ldc, int64_t sA, int64_t sB, int64_t sC,
+                                                  const int* __restrict__ done) {
+  DONE_GUARD(done);
+  constexpr int BM = 32, BN = 32, BK = 16;
+  __shared__ double As[BK][BM + 2];
+  __shared__ double Bs[BK][BN + 2];
+  A += sA * blockIdx.z;
+  B += sB * blockIdx.z;
+  C += sC * blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + 256 * e;
+      {
+        const int row = idx / BK, kk = idx % BK;
+        const int gm = m0 + row, gk = k0 + kk;
+        As[kk][row] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
+      }
+      if (BT) {
+        const int row = idx / BK, kk = idx % BK;
+        const int gn = n0 + row, gk = k0 + kk;
+        Bs[kk][row] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+      } else {
+        const int kk = idx / BN, col = idx % BN;
+        const int gn = n0 + col, gk = k0 + kk;
+        Bs[kk][col] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      const double a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
+      const double b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+      c00 = fma(a0, b0, c00);
+      c01 = fma(a0, b1, c01);
+      c10 = fma(a1, b0, c10);
+      c11 = fma(a1, b1, c11);
+    }
+    __syncthreads();
+  }
+  const int gm = m0 + ty * 2, gn = n0 + tx * 2;
+  if (gm < M) {
+    if (gn < N) C[(int64_t)gm * ldc + gn] = c00;
+    if (gn + 1 < N) C[(int64_t)gm * ldc + gn + 1] = c01;
+  }
+  if (gm + 1 < M) {
+    if (gn < N) C[(int64_t)(gm + 1) * ldc + gn] = c10;
+    if (gn + 1 < N) C[(int64_t)(gm + 1) * ldc + gn + 1] = c11;
+  }
+}
+
+static int dct2d_launch(fh_context* ctx, const double* in, double* out, int planes, int inverse, const int* done,
+                        hipStream_t st) {
+  const int S = ctx->S;
+  if (planes > ctx->planes_max) return FH_ESIZE;
+  const double* b1 = inverse ? ctx->basis_t : ctx->basis;
+  // pass 1 (along W): T[r][k] = sum_n X[r][n] * b1[k][n]
+  {
+    dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
+    hipLaunchKernelGGL(k_gemm_f64<true>, grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                       (int64_t)0, (int64_t)0, (int64_t)0, done);
+  }
+  // pass 2 (along H), per plane: Y[k][w] = sum_n b1[k][n] * T[n][w]
+  {
+    dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
+    hipLaunchKernelGGL(k_gemm_f64<false>, grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, done);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Representation apply:  out = D.*z + r.*(B (M (B^T (r.*z))))
+//   pass 1  k_rep_dots   : block partials of t = B^T (r.*z), 16 columns per sweep held in registers
+//   pass 1b k_rep_coef   : t = sum of partials, c = M t                    (one workgroup)
+//   pass 2  k_rep_apply2 : out = D.*z + r.*(B c)
+// B is read twice; pass 2 walks the rows in the opposite order so that the tail of pass 1 is still
+// in the Infinity Cache / L2 when it is needed again.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDotRows = 512;  // rows per workgroup in the dots pass (256 threads x 2)
+constexpr int kColGroup = 16;
+
+__global__ __launch_bounds__(256) void k_rep_dots(const double* __restrict__ B, const double* __restrict__ r,
+                                                  const double* __restrict__ z, double* __restrict__ partial,
+                                                  int64_t d, int m, const int* __restrict__ done) {
+  DONE_GUARD(done);
+  __shared__ double red[4][kColGroup];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
+  double2 rz = make_double2(0.0, 0.0);
+  const bool ok = i0 + 1 < d;  // d is even (3*S*S), rows handled in pairs
+  if (ok) {
+    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
+    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+    rz = make_double2(zz.x * rr.x, zz.y * rr.y);
+  }
+  for (int j0 = 0; j0 < m; j0 += kColGroup) {
+    double acc[kColGroup];
+#pragma unroll
+    for (int j = 0; j < kColGroup; ++j) {
+      acc[j] = 0.0;
+      if (ok && j0 + j < m) {
+        const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)(j0 + j) * d + i0);
+        acc[j] = fma(b.x, rz.x, b.y * rz.y);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kColGroup; ++j) acc[j] = wave_sum(acc[j]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < kColGroup; ++j) red[w][j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < kColGroup && j0 + tid < m)
+      partial[(int64_t)blockIdx.x * FH_MAX_COLS + j0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rep_coef(const double* __restrict__ partial, int nblocks,
+                                                  const double* __restrict__ M, int ldm, int m,
+                                                  double* __restrict__ coef, const int* __restrict__ done) {
+  DONE_GUARD(done);
+  __shared__ double t[FH_MAX_COLS];
+  const int j = threadIdx.x;
+  if (j < m) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * FH_MAX_COLS + j];
+    t[j] = s;
+  }
+  __syncthreads();
+  if (j < m) {
+    double s = 0.0;
+    for (int l = 0; l < m; ++l) s = fma(M[(int64_t)j * ldm + l], t[l], s);
+    coef[j] = s;
+    coef[FH_MAX_COLS + j] = t[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_rep_apply2(const double* __restrict__ D, const double* __restrict__ r,
+                                                    const double* __restrict__ B, const double* __restrict__ coef,
+                                                    const double* __restrict__ z, double* __restrict__ out,
+                                                    int64_t d, int m, const int* __restrict__ done) {
+  DONE_GUARD(done);
+  __shared__ double c[FH_MAX_COLS];
+  for (int j = threadIdx.x; j < m; j += 256) c[j] = coef[j];
+  __syncthreads();
+  const int64_t nb = gridDim.x;
+  const int64_t blk = nb - 1 - blockIdx.x;  // reverse sweep (see header comment)
+  const int64_t i0 = blk * kDotRows + 2 * threadIdx.x;
+  if (i0 + 1 >= d) return;
+  double2 acc = make_double2(0.0, 0.0);
+  for (int j = 0; j < m; ++j) {
+    const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
+    const double cj = c[j];
+    acc.x = fma(b.x, cj, acc.x);
+    acc.y = fma(b.y, cj, acc.y);
+  }
+  const double2 zz = *reinterpret_cast<const double2*>(z + i0);
+  const double2 dd = *reinterpret_cast<const double2*>(D + i0);
+  double2 o;
+  if (m > 0) {
+    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+    o = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
+  } else {
+    o = make_double2(dd.x * zz.x, dd.y * zz.y);
+  }
+  *reinterpret_cast<double2*>(out + i0) = o;
+}
+
+static int rep_apply_launch(fh_context* ctx, const double* D, const double* r, const double* B, const double* M,
+                            int ldm, const double* z, double* out, int64_t d, int m, const int* done,
+                            hipStream_t st) {
+  if (m < 0 || m > FH_MAX_COLS || (d & 1)) return FH_ESIZE;
+  const int nb = (int)((d + kDotRows - 1) / kDotRows);
+  if (nb > kPartialRows) return FH_ESIZE;
+  if (m > 0) {
+    hipLaunchKernelGGL(k_rep_dots, dim3(nb), dim3(256), 0, st, B, r, z, ctx->partial, d, m, done);
+    hipLaunchKernelGGL(k_rep_coef, dim3(1), dim3(256), 0, st, (const double*)ctx->partial, nb, M, ldm, m,
+                       ctx->coef, done);
+  }
+  hipLaunchKernelGGL(k_rep_apply2, dim3(nb), dim3(256), 0, st, D, r, B, (const double*)ctx->coef, z, out, d, m,
+                     done);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Representation inverse (Woodbury) - diagonal part + weighted Gram  G = B^T diag(rx^2/Dx) B.
+//   k_invert_diag : Dx += shift, Dy = 1/Dx, ry = rx/Dx
+//   k_gram        : grid (row blocks, 64x64 tile pairs ta<=tb); each workgroup streams its rows in
+//                   chunks of 64 through LDS and keeps a 4x4 register tile per thread
+//   k_gram_reduce : sums the row-block partials, writes both triangles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, const double* __restrict__ rx,
+                                                     double shift, double* __restrict__ Dy, double* __restrict__ ry,
+                                                     int64_t d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= d) return;
+  const double v = Dx[i] + shift;
+  Dx[i] = v;
+  Dy[i] = 1.0 / v;
+  if (rx != nullptr) ry[i] = rx[i] / v;
+}
+
+constexpr int kGramRowBlocks = 192;
+constexpr int kGT = 64;  // Gram tile edge and row-chunk length
+
+__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, const double* __restrict__ rx,
+                                              const double* __restrict__ Dx, double* __restrict__ gpartial,
+                                              int64_t d, int m, int ntiles) {
+  __shared__ double As[kGT][kGT + 1];  // [row][col of tile a], weighted
+  __shared__ double Bs[kGT][kGT + 1];  // [row][col of tile b]
+  // decode tile pair
+  int ta = 0, tb = 0, p = blockIdx.y;
+  for (ta = 0; ta < ntiles; ++ta) {
+    const int cnt = ntiles - ta;
+    if (p < cnt) {
+      tb = ta + p;
+      break;
+    }
+    p -= cnt;
+  }
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t rows_per = ((d + gridDim.x - 1) / gridDim.x + kGT - 1) / kGT * kGT;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+  const int64_t r1 = r0 + rows_per < d ? r0 + rows_per : d;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int64_t c0 = r0; c0 < r1; c0 += kGT) {
+    // load 64 rows x 64 cols of each tile: thread -> (col = e*4 + tid/64, row = tid%64): coalesced along rows
+#pragma unroll 4
+    for (int e = 0; e < 16; ++e) {
+      const int col = e * 4 + (tid >> 6), row = tid & 63;
+      const int64_t gi = c0 + row;
+      const int ja = ta * kGT + col, jb = tb * kGT + col;
+      double va = 0.0, vb = 0.0;
+      if (gi < r1) {
+        const double wgt = rx[gi] * rx[gi] / Dx[gi];
+        if (ja < m) va = B[(int64_t)ja * d + gi] * wgt;
+        if (jb < m) vb = B[(int64_t)jb * d + gi];
+      }
+      As[row][col] = va;
+      Bs[row][col] = vb;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int row = 0; row < kGT; ++row) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = As[row][ty * 4 + q];
+        b[q] = Bs[row][tx * 4 + q];
+      }
+#pragma unroll
+      for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = fma(a[qa], b[qb], acc[qa][qb]);
+    }
+    __syncthreads();
+  }
+  double* dst = gpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
+#pragma unroll
+  for (int qa = 0; qa < 4; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) dst[(ty * 4 + qa) * kGT + tx * 4 + qb] = acc[qa][qb];
+}
+
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ gpartial, int nrb, int ntiles, int m,
+                                                     double* __restrict__ G, int ldg) {
+  // one workgroup per tile pair; 4096 outputs, 16 per thread
+  int ta = 0, tb = 0, p = blockIdx.x;
+  for (ta = 0; ta < ntiles; ++ta) {
+    const int cnt = ntiles - ta;
+    if (p < cnt) {
+      tb = ta + p;
+      break;
+    }
+    p -= cnt;
+  }
+  const double* src = gpartial + (int64_t)blockIdx.x * nrb * (kGT * kGT);
+  for (int o = threadIdx.x; o < kGT * kGT; o += 256) {
+    double s = 0.0;
+    for (int b = 0; b < nrb; ++b) s += src[(int64_t)b * (kGT * kGT) + o];
+    const int a = ta * kGT + o / kGT, c = tb * kGT + o % kGT;
+    if (a < m && c < m) {
+      G[(int64_t)a * ldg + c] = s;
+      if (ta != tb) G[(int64_t)c * ldg + a] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Elementwise helpers and scalar reductions
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_axpby(double alpha, const double* __restrict__ a, double beta,
+                                               const double* __restrict__ b, double* __restrict__ out, int64_t n,
+                                               const int* __restrict__ done) {
+  DONE_GUARD(done);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double v = alpha * a[i];
+    if (b != nullptr) v = fma(beta, b[i], v);
+    out[i] = v;
+  }
+}
+
+// out = mask .* in  (add == null)   |   out = add_scale*add + mask .* in
+__global__ __launch_bounds__(256) void k_mask(const double* __restrict__ mask, const double* __restrict__ in,
+                                              const double* __restrict__ add, double add_scale,
+                                              double* __restrict__ out, int64_t n, const int* __restrict__ done) {
+  DONE_GUARD(done);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double v = mask[i] * in[i];
+    if (add != nullptr) v = fma(add_scale, add[i], v);
+    out[i] = v;
+  }
+}
+
+constexpr int kDotBlocks = 256;
+
+// partial[b] = sum over block b of a.*b ; optional second product a2.*b2 -> partial[kDotBlocks + b]
+__global__ __launch_bounds__(256) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
+                                                     const double* __restrict__ a2, const double* __restrict__ b2,
+                                                     double* __restrict__ part, int64_t n,
+                                                     const int* __restrict__ done) {
+  DONE_GUARD(done);
+  __shared__ double red[4];
+  double s = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    s = fma(a[i], b[i], s);
+    if (a2 != nullptr) s2 = fma(a2[i], b2[i], s2);
+  }
+  s = block_sum_256(s, red);
+  if (a2 != nullptr) s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    if (a2 != nullptr) part[kDotBlocks + blockIdx.x] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scalar_reduce(const double* __restrict__ part, int nparts,
+                                                       double* __restrict__ dst) {
+  __shared__ double red[4];
+  double s = threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) *dst = s;
+}
+
+__global__ __launch_bounds__(256) void k_space_prep(const double* __restrict__ dm, double s2,
+                                                    const double* __restrict__ dx, double* __restrict__ de,
+                                                    double* __restrict__ part, int64_t n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double e = s2 * dm[i];
+    de[i] = e;
+    s = fma(dx[i], e, s);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__ de, const double* __restrict__ cdx,
+                                                      double gamma, double q, double s2, double* __restrict__ Dc,
+                                                      const double* __restrict__ rc, double* __restrict__ bc0,
+                                                      double* __restrict__ bc1, double* __restrict__ Dh,
+                                                      const double* __restrict__ rh, double* __restrict__ bh0,
+                                                      double* __restrict__ bh1, int project, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double e = de[i], c = cdx[i];
+    double dc = Dc[i];
+    if (project) {
+      dc = dc + gamma * e * e - c * c / q;
+      Dc[i] = dc;
+    } else {
+      const double s = (rc != nullptr) ? rc[i] : 1.0;
+      bc0[i] = e / s;
+      bc1[i] = c / s;
+    }
+    Dh[i] = (dc / s2 - 1.0) / s2;
+    const double sh = (rh != nullptr) ? rh[i] : 1.0;
+    bh0[i] = e / sh;
+    bh1[i] = c / sh;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Circular convolution with a sparse tap list.
+//   k_conv_tile   : stride-1 output grid (blur, blur^T, and blur^T of a zero-inserted LR image):
+//                   16x32 output tile + halo staged in LDS (<= 56 KiB at halo 30), 2 outputs per
+//                   thread, taps read through the scalar path (uniform index).
+//   k_conv_direct : decimated forward (SR: out[i][j] sampled at (i*stride, j*stride)).
+// Epilogue: out = acc + add_scale * add  when add != null  (the sigma_y^2 u term of A_mm).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in, double* __restrict__ out,
+                                                   const int* __restrict__ tdy, const int* __restrict__ tdx,
+                                                   const double* __restrict__ tw, int ntaps, int S, int halo,
+                                                   int adjoint, int up, const double* __restrict__ add,
+                                                   double add_scale, const int* __restrict__ done) {
+  DONE_GUARD(done);
+  extern __shared__ __align__(16) double tile[];
+  const int sw = 32 + 2 * halo, sh = 16 + 2 * halo;
+  const int plane = blockIdx.z;
+  const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 32;
+  const int Sin = S / up;
+  const double* src = in + (int64_t)plane * Sin * Sin;
+  for (int idx = threadIdx.x; idx < sw * sh; idx += 256) {
+    const int ly = idx / sw, lx = idx % sw;
+    int gy = (oy0 + ly - halo) % S, gx = (ox0 + lx - halo) % S;
+    gy += gy < 0 ? S : 0;
+    gx += gx < 0 ? S : 0;
+    double v;
+    if (up == 1) {
+      v = src[(int64_t)gy * S + gx];
+    } else {
+      v = ((gy % up) == 0 && (gx % up) == 0) ? src[(int64_t)(gy / up) * Sin + gx / up] : 0.0;
+    }
+    tile[idx] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // ly in [0,8): rows ly, ly+8
+  const int sgn = adjoint ? 1 : -1;
+  double a0 = 0, a1 = 0;
+  const int base = (ly + halo) * sw + lx + halo;
+  for (int t = 0; t < ntaps; ++t) {
+    const int off = sgn * (tdy[t] * sw + tdx[t]);
+    const double w = tw[t];
+    const double* q = tile + base + off;
+    a0 = fma(w, q[0], a0);
+    a1 = fma(w, q[8 * sw], a1);
+  }
+  const int ox = ox0 + lx;
+  if (ox >= S) return;
+  double acc[2] = {a0, a1};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int oy = oy0 + ly + 8 * e;
+    if (oy < S) {
+      const int64_t o = (int64_t)plane * S * S + (int64_t)oy * S + ox;
+      double v = acc[e];
+      if (add != nullptr) v = fma(add_scale, add[o], v);
+      out[o] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ in, double* __restrict__ out,
+                                                     const int* __restrict__ tdy, const int* __restrict__ tdx,
+                                                     const double* __restrict__ tw, int ntaps, int S, int stride,
+                                                     int planes, const double* __restrict__ add, double add_scale,
+                                                     const int* __restrict__ done) {
+  DONE_GUARD(done);
+  const int So = S / stride;
+  const int64_t total = (int64_t)planes * So * So;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= total) return;
+  const int plane = (int)(o / ((int64_t)So * So));
+  const int rem = (int)(o % ((int64_t)So * So));
+  const int oy = (rem / So) * stride, ox = (rem % So) * stride;
+  const double* src = in + (int64_t)plane * S * S;
+  double acc = 0.0;
+  for (int t = 0; t < ntaps; ++t) {
+    int gy = (oy - tdy[t]) % S, gx = (ox - tdx[t]) % S;
+    gy += gy < 0 ? S : 0;
+    gx += gx < 0 ? S : 0;
+    acc = fma(tw[t], src[(int64_t)gy * S + gx], acc);
+  }
+  if (add != nullptr) acc = fma(add_scale, add[o], acc);
+  out[o] = acc;
+}
+
+static int conv_launch(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
+                       const double* w, int ntaps, int halo, int planes, int stride, int adjoint, const double* add,
+                       double add_scale, const int* done, hipStream_t st) {
+  const int S = ctx->S;
+  if (stride < 1 || S % stride != 0 || halo < 0 || halo > 32) return FH_EINVAL;
+  if (!adjoint && stride > 1) {
+    const int So = S / stride;
+    const int64_t total = (int64_t)planes * So * So;
+    hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, dy, dx, w,
+                       ntaps, S, stride, planes, add, add_scale, done);
+  } else {
+    const size_t lds = (size_t)(32 + 2 * halo) * (16 + 2 * halo) * sizeof(double);
+    dim3 grid((S + 31) / 32, (S + 15) / 16, planes);
+    hipLaunchKernelGGL(k_conv_tile, grid, dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, halo, adjoint,
+                       adjoint ? stride : 1, add, add_scale, done);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A_mm(u) = sigma_y^2 u + A C A^T u       (conditioning_mechanisms.py:395-400, 505-511, 653-659)
+// ------------------------------------------------------------------------------------------------
+static int amm_launch(fh_context* ctx, const fh_problem* p, const double* u, double* out, const int* done,
+                      hipStream_t st) {
+  const int S = ctx->S;
+  const int64_t d = p->d;
+  if (d != (int64_t)p->planes * S * S) return FH_EINVAL;
+  int rc;
+  double *w0 = ctx->w0, *w1 = ctx->w1;
+  const int halo = p->halo;
+  // w0 = A^T u
+  if (p->op == 0) {
+    hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, u, (const double*)nullptr, 0.0, w0, d, done);
+  } else {
+    rc = conv_launch(ctx, u, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 1, nullptr,
+                     0.0, done, st);
+    if (rc) return rc;
+  }
+  // w0 <- C w0  (through the DCT basis when the covariance lives there)
+  if (p->use_dct) {
+    rc = dct2d_launch(ctx, w0, w1, p->planes, 0, done, st);
+    if (rc) return rc;
+    rc = rep_apply_launch(ctx, p->D, p->r, p->B, p->M, p->ldm, w1, w0, d, p->m, done, st);
+    if (rc) return rc;
+    rc = dct2d_launch(ctx, w0, w1, p->planes, 1, done, st);
+    if (rc) return rc;
+  } else {
+    rc = rep_apply_launch(ctx, p->D, p->r, p->B, p->M, p->ldm, w0, w1, d, p->m, done, st);
+    if (rc) return rc;
+  }
+  // out = sigma_y^2 u + A w1
+  if (p->op == 0) {
+    hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, (const double*)w1, u, p->sigma_y2, out, d,
+                       done);
+  } else {
+    rc = conv_launch(ctx, w1, out, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 0, u,
+                     p->sigma_y2, done, st);
+    if (rc) return rc;
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conjugate gradients, conditioning_utils/cg.py:232-282 (M = I, x0 = b).  Scalars stay on the device;
+// the two reductions per iteration are block partials re-summed by every workgroup of the next kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCgBlocks = 192;
+
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* red) {
+  double s = threadIdx.x < n ? part[threadIdx.x] : 0.0;
+  return block_sum_256(s, red);
+}
+
+// r = b - Ab ; p = r ; x = b ; partial r.r and b.b
+__global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, const double* __restrict__ Ab,
+                                                 double* __restrict__ x, double* __restrict__ r,
+                                                 double* __restrict__ p, double* __restrict__ part, int64_t n) {
+  __shared__ double red[4];
+  double srr = 0.0, sbb = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double bi = b[i], ri = bi - Ab[i];
+    x[i] = bi;
+    r[i] = ri;
+    p[i] = ri;
+    srr = fma(ri, ri, srr);
+    sbb = fma(bi, bi, sbb);
+  }
+  srr = block_sum_256(srr, red);
+  sbb = block_sum_256(sbb, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = srr;
+    part[kDotBlocks + blockIdx.x] = sbb;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ part, int nparts, double rtol,
+                                                     double atol, fh_cg_state* __restrict__ stt,
+                                                     double* __restrict__ rzbuf) {
+  __shared__ double red[4];
+  const double srr = sum_partials(part, nparts, red);
+  const double sbb = sum_partials(part + kDotBlocks, nparts, red);
+  if (threadIdx.x == 0) {
+    rzbuf[0] = srr;
+    stt->rz = srr;
+    stt->rnorm = sqrt(srr);
+    stt->bnorm = sqrt(sbb);
+    const double s = rtol * sqrt(sbb);
+    stt->stop = s > atol ? s : atol;
+    stt->done = 0;
+    stt->niter = 0;
+    stt->optimal = 0;
+  }
+}
+
+// iteration k, first half: pAp check, x += alpha p, r -= alpha Ap, partial r.r
+__global__ __launch_bounds__(256) void k_cg_step1(const double* __restrict__ p, const double* __restrict__ ap,
+                                                  double* __restrict__ x, double* __restrict__ r,
+                                                  const double* __restrict__ part_pap, int nparts,
+                                                  double* __restrict__ part_rr, const double* __restrict__ rzbuf,
+                                                  fh_cg_state* __restrict__ stt, int k, int64_t n) {
+  if (stt->done) return;
+  __shared__ double red[4];
+  const double pAp = sum_partials(part_pap, nparts, red);
+  if (pAp <= 1e-16) {  // cg.py:250 - also catches NaN-free breakdowns; x, r keep their previous values
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      stt->pAp = pAp;
+      stt->niter = k;
+      stt->done = 2;
+    }
+    return;
+  }
+  const double alpha = rzbuf[(k - 1) & 1] / pAp;
+  double srr = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    x[i] = fma(alpha, p[i], x[i]);
+    const double ri = fma(-alpha, ap[i], r[i]);
+    r[i] = ri;
+    srr = fma(ri, ri, srr);
+  }
+  srr = block_sum_256(srr, red);
+  if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+}
+
+// iteration k, second half: stopping test, p = r + beta p
+__global__ __launch_bounds__(256) void k_cg_step2(const double* __restrict__ r, double* __restrict__ p,
+                                                  const double* __restrict__ part_rr, int nparts,
+                                                  double* __restrict__ rzbuf, fh_cg_state* __restrict__ stt, int k,
+                                                  int64_t n) {
+  if (stt->done) return;
+  __shared__ double red[4];
+  const double rz_new = sum_partials(part_rr, nparts, red);
+  const double rnorm = sqrt(rz_new);
+  if (rnorm <= stt->stop) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      stt->rnorm = rnorm;
+      stt->niter = k;
+      stt->optimal = 1;
+      stt->done = 1;
+    }
+    return;
+  }
+  const double beta = rz_new / rzbuf[(k - 1) & 1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    p[i] = fma(beta, p[i], r[i]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rzbuf[k & 1] = rz_new;
+    stt->rnorm = rnorm;
+    stt->niter = k;
+  }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int fh_version(void) { return 100; }
+
+int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
+  if (out == nullptr || S < 2 || S > 256 || (S & 1) || planes_max < 1 || m_cap < 0 || m_cap > FH_MAX_COLS)
+    return FH_EINVAL;
+  fh_context* c = new fh_context();
+  memset(c, 0, sizeof(*c));
+  c->S = S;
+  c->planes_max = planes_max;
+  c->m_cap = m_cap;
+  const size_t nimg = (size_t)planes_max * S * S;
+  std::vector<double> bas((size_t)S * S), bast((size_t)S * S);
+  for (int k = 0; k < S; ++k) {
+    const long double sk = k == 0 ? sqrtl(1.0L / S) : sqrtl(2.0L / S);
+    for (int n = 0; n < S; ++n) {
+      const long double v = sk * cosl(M_PIl * (2 * n + 1) * k / (2.0L * S));
+      bas[(size_t)k * S + n] = (double)v;
+      bast[(size_t)n * S + k] = (double)v;
+    }
+  }
+  const int ntiles = (m_cap + kGT - 1) / kGT;
+  const int npairs = ntiles * (ntiles + 1) / 2;
+  c->gpartial_elems = (int64_t)(npairs > 0 ? npairs : 1) * kGramRowBlocks * kGT * kGT;
+  FH_CHECK(hipMalloc(&c->basis, sizeof(double) * S * S));
+  FH_CHECK(hipMalloc(&c->basis_t, sizeof(double) * S * S));
+  FH_CHECK(hipMemcpy(c->basis, bas.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
+  FH_CHECK(hipMemcpy(c->basis_t, bast.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
+  FH_CHECK(hipMalloc(&c->tmp_img, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS));
+  FH_CHECK(hipMalloc(&c->gpartial, sizeof(double) * c->gpartial_elems));
+  FH_CHECK(hipMalloc(&c->coef, sizeof(double) * 2 * FH_MAX_COLS));
+  FH_CHECK(hipMalloc(&c->cg_r, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->cg_p, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->cg_ap, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->w0, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->w1, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->w2, sizeof(double) * (4 * kDotBlocks + 16)));
+  FH_CHECK(hipMalloc(&c->cg_state, sizeof(fh_cg_state)));
+  FH_CHECK(hipMemset(c->cg_state, 0, sizeof(fh_cg_state)));
+  *out = c;
+  return 0;
+}
+
+int fh_context_destroy(fh_context* c) {
+  if (c == nullptr) return 0;
+  void* bufs[] = {c->basis, c->basis_t, c->tmp_img, c->partial, c->gpartial, c->coef, c->cg_r,
+                  c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete c;
+  return 0;
+}
+
+int fh_dct2d(fh_context* ctx, const double* in, double* out, int planes, int inverse, void* stream) {
+  if (!ctx || !in || !out || planes < 1) return FH_EINVAL;
+  return dct2d_launch(ctx, in, out, planes, inverse, nullptr, (hipStream_t)stream);
+}
+
+int fh_rep_apply(fh_context* ctx, const double* D, const double* r, const double* B, const double* M, int ldm,
+                 const double* z, double* out, int64_t d, int m, void* stream) {
+  if (!ctx || !D || !z || !out || d < 2) return FH_EINVAL;
+  if (m > 0 && (!r || !B || !M || ldm < m)) return FH_EINVAL;
+  return rep_apply_launch(ctx, D, r, B, M, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
+}
+
+int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,
+                  double* ry, double* G, int ldg, int64_t d, int m, void* stream) {
+  if (!ctx || !Dx || !Dy || d < 1 || m < 0 || m > ctx->m_cap) return FH_EINVAL;
+  if (m > 0 && (!rx || !ry || !B || !G || ldg < m)) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (m > 0) {
+    // Gram uses the shifted diagonal: apply the shift first, then read Dx
+    hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
+    const int ntiles = (m + kGT - 1) / kGT;
+    const int npairs = ntiles * (ntiles + 1) / 2;
+    if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems) return FH_ESIZE;
+    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, st, B, rx, (const double*)Dx,
+                       ctx->gpartial, d, m, ntiles);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
+                       ntiles, m, G, ldg);
+  } else {
+    hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_space_prep(fh_context* ctx, const double* dm, double s2, const double* dx, double* de, double* scal,
+                  int64_t d, void* stream) {
+  if (!ctx || !dm || !dx || !de || !scal) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_space_prep, dim3(kDotBlocks), dim3(256), 0, st, dm, s2, dx, de, ctx->w2, d);
+  hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, st, (const double*)ctx->w2, kDotBlocks, scal);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_dot(fh_context* ctx, const double* a, const double* b, double* scal, int slot, int64_t d, void* stream) {
+  if (!ctx || !a || !b || !scal || slot < 0) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_dot_partial, dim3(kDotBlocks), dim3(256), 0, st, a, b, (const double*)nullptr,
+                     (const double*)nullptr, ctx->w2, d, (const int*)nullptr);
+  hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, st, (const double*)ctx->w2, kDotBlocks, scal + slot);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double gamma, double q, double s2,
+                    double* Dc, const double* rc, double* Bc_col0, double* Bc_col1, double* Dh, const double* rh,
+                    double* Bh_col0, double* Bh_col1, int project, int64_t d, void* stream) {
+  if (!ctx || !de || !cdx || !Dc || !Dh || !Bh_col0 || !Bh_col1) return FH_EINVAL;
+  if (!project && (!Bc_col0 || !Bc_col1)) return FH_EINVAL;
+  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, gamma, q, s2, Dc, rc,
+                     Bc_col0, Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_axpby(double alpha, const double* a, double beta, const double* b, double* out, int64_t n, void* stream) {
+  if (!a || !out || n < 1) return FH_EINVAL;
+  hipLaunchKernelGGL(k_axpby, dim3(512), dim3(256), 0, (hipStream_t)stream, alpha, a, beta, b, out, n,
+                     (const int*)nullptr);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_read_scalars(const double* scal, double* out_host, int k, void* stream) {
+  if (!scal || !out_host || k < 1) return FH_EINVAL;
+  FH_CHECK(hipMemcpyAsync(out_host, scal, sizeof(double) * k, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int fh_conv_circ(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
+                 const double* w, int ntaps, int halo, int planes, int stride, int adjoint, void* stream) {
+  if (!ctx || !in || !out || !dy || !dx || !w || ntaps < 1 || planes < 1) return FH_EINVAL;
+  return conv_launch(ctx, in, out, dy, dx, w, ntaps, halo, planes, stride, adjoint, nullptr, 0.0, nullptr,
+                     (hipStream_t)stream);
+}
+
+int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, void* stream) {
+  if (!ctx || !p || !u || !out) return FH_EINVAL;
+  return amm_launch(ctx, p, u, out, nullptr, (hipStream_t)stream);
+}
+
+int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
+                int maxiter, fh_cg_info* info, void* stream) {
+  if (!ctx || !p || !b || !x || !info || maxiter < 1 || !(rtol > 0 || atol > 0)) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = ctx->S;
+  const int So = S / (p->op == 2 ? p->stride : 1);
+  const int64_t n = (int64_t)p->planes * So * So;  // measurement dimension
+  double *r = ctx->cg_r, *pk = ctx->cg_p, *ap = ctx->cg_ap;
+  double* part = ctx->w2;                      // [0,256) pAp / init r.r ; [256,512) init b.b ; [512,768) r.r
+  double* rzbuf = ctx->w2 + 4 * kDotBlocks;    // [2]
+  fh_cg_state* stt = ctx->cg_state;
+  const int* done = &stt->done;
+  int rc = amm_launch(ctx, p, b, ap, nullptr, st);  // A x0 with x0 = b
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_cg_init, dim3(kCgBlocks), dim3(256), 0, st, b, (const double*)ap, x, r, pk, part, n);
+  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(256), 0, st, (const double*)part, kCgBlocks, rtol, atol, stt,
+                     rzbuf);
+  fh_cg_state h;
+  memset(&h, 0, sizeof(h));
+  int k = 0;
+  const int chunk = 8;
+  while (k < maxiter && !h.done) {
+    const int kend = k + chunk < maxiter ? k + chunk : maxiter;
+    for (; k < kend;) {
+      ++k;
+      rc = amm_launch(ctx, p, pk, ap, done, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_dot_partial, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap,
+                         (const double*)nullptr, (const double*)nullptr, part, n, done);
+      hipLaunchKernelGGL(k_cg_step1, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
+                         (const double*)part, kCgBlocks, part + 2 * kDotBlocks, (const double*)rzbuf, stt, k, n);
+      hipLaunchKernelGGL(k_cg_step2, dim3(kCgBlocks), dim3(256), 0, st, (const double*)r, pk,
+                         (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, k, n);
+    }
+    FH_CHECK(hipMemcpyAsync(&h, stt, sizeof(h), hipMemcpyDeviceToHost, st));
+    FH_CHECK(hipStreamSynchronize(st));
+  }
+  FH_LAUNCH_CHECK();
+  info->niter = h.done ? h.niter : maxiter;
+  info->optimal = h.optimal;
+  info->residual_norm = h.rnorm;
+  info->b_norm = h.bnorm;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""The Free Hunch ODE sampler (reference: generate_conditional.py:38-220): EDM sigma grid snapped to the
+network's table, Euler/Heun loop in float64, one plugin instance per image."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .conditioning_mechanisms import choose_conditioning_mechanism
+from .measurements import get_operator
+
+
+def get_sigma_steps(discretization, num_steps, sigma_min, sigma_max, rho, device=None):
+    if discretization != "edm":
+        raise NotImplementedError("only the 'edm' discretisation is on the Free Hunch path")
+    i = torch.arange(num_steps, dtype=torch.float64, device=device)
+    return (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+
+
+class StackedRandomGenerator:
+    """One torch.Generator per seed (generate_conditional.py:206-220)."""
+
+    def __init__(self, device, seeds):
+        self.generators = [torch.Generator(device).manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+
+    def randn(self, size, **kwargs):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randn(size[1:], generator=gen, **kwargs) for gen in self.generators])
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
+
+
+class StandardRGBEncoder:  # training/encoders.py:61-73
+    def encode(self, x):
+        return x.to(torch.float32) / 127.5 - 1
+
+    def decode(self, x):
+        return (x.to(torch.float32) * 127.5 + 128).clip(0, 255).to(torch.uint8)
+
+
+def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=None, labels=None,
+                        randn_like=torch.randn_like, num_steps=18, sigma_min=None, sigma_max=None, rho=7,
+                        solver="heun", discretization="edm", schedule="linear", scaling="none", S_churn=0, S_min=0,
+                        S_max=float("inf"), S_noise=1, measurement=None, operator=None, **other_args):
+    """Returns (x_final float64, [x_0], y).  `measurement`/`operator` (not in the reference) inject a fixed y and a
+    pre-built operator so that runs are reproducible across devices; otherwise y = A x + noise is drawn here."""
+    assert solver in ["euler", "heun"]
+    if schedule != "linear" or scaling != "none":
+        raise NotImplementedError("only sigma(t)=t, s(t)=1 (the reference's defaults) are on the Free Hunch path")
+    forward_operator = operator if operator is not None else get_operator(**operator_kwargs)
+    if measurement is None:
+        cond_images = forward_operator.forward(cond_images, noiseless=False)
+    else:
+        cond_images = measurement
+    sigma_min = 0.002 if sigma_min is None else sigma_min
+    sigma_max = 80 if sigma_max is None else sigma_max
+    sigma_min, sigma_max = max(sigma_min, net.sigma_min), min(sigma_max, net.sigma_max)
+    sigma_steps = get_sigma_steps(discretization, num_steps, sigma_min, sigma_max, rho, noise.device)
+    t_steps = net.round_sigma(sigma_steps)
+    t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
+    t_list = [float(t) for t in t_steps]  # host copies: the loop's scalar arithmetic stays in float64 on the CPU
+
+    x_next = noise.to(torch.float64) * t_list[0]
+    x_all = [x_next.detach()]
+    o = other_args
+    mech = choose_conditioning_mechanism(o["conditioning_mechanism"])(
+        o["cond_scaling"], forward_operator, o["clip_x0_mean"], init_denoiser_variance=1,
+        init_noise_variance=torch.tensor(t_list[0], dtype=torch.float64) ** 2, data_dim=x_next.shape[1:].numel(),
+        pigdm_posthoc_scaling=o.get("pigdm_posthoc_scaling", False), max_vector_count=o["max_vector_count"],
+        data_dir=o["dataset_path"], image_base_covariance=o["image_base_covariance"],
+        pca_component_count=o.get("pca_component_count", 10),
+        denoiser_mean_error_threshold=o["denoiser_mean_error_threshold"],
+        use_analytical_score_time_update=o["use_analytical_score_time_update"],
+        project_to_diagonal=o["project_to_diagonal"], space_step_update_threshold=o["space_step_update_threshold"],
+        space_step_update_lower_threshold=o["space_step_update_lower_threshold"], max_rtol=o["max_rtol"],
+        do_space_updates=o["do_space_updates"], use_analytic_var_at_end=o.get("use_analytic_var_at_end", False),
+        solver_type=o.get("solver_type", "customcuda"), use_rtol_func=o.get("use_rtol_func", False),
+        diffpir_lambda=o.get("diffpir_lambda", 10.0))
+    y = cond_images.to(noise.device)
+    f64 = lambda v: torch.tensor(v, dtype=torch.float64, device=noise.device)
+    for i, (t_cur, t_next) in enumerate(zip(t_list[:-1], t_list[1:])):
+        x_cur = x_next
+        gamma = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
+        t_hat = float(net.round_sigma(f64(t_cur + gamma * t_cur)))
+        churn = max(t_hat ** 2 - t_cur ** 2, 0.0) ** 0.5
+        x_hat = x_cur + churn * S_noise * randn_like(x_cur) if churn > 0 else x_cur
+        h = t_next - t_hat
+        with torch.enable_grad():
+            denoised = mech(x_hat.detach(), net, y, f64(t_hat))
+        score = -(x_hat - denoised) / t_hat ** 2
+        d_cur = -score * t_hat
+        x_prime = x_hat + h * d_cur
+        t_prime = t_hat + h  # may differ from t_next by one ulp, exactly as in the reference (:150)
+        if solver == "euler" or i == num_steps - 1:
+            x_next = x_hat + h * d_cur
+        else:
+            with torch.enable_grad():
+                denoised = mech(x_prime.detach(), net, y, f64(t_prime))
+            d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * denoised
+            x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
+    conditional_sampler.last_mechanism = mech
+    return x_next, x_all, cond_images

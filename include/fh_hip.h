@@ -1,0 +1,130 @@
+/*
+ * fh_hip.h - C ABI of libfh_hip.so: the MI355X (gfx950) kernels of the Free Hunch guided-sampling
+ * hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless its name ends
+ * in `_host`.  Every entry point returns 0 on success, a hipError_t value (>0) on a HIP failure or a
+ * negative FH_E* code on bad arguments; nothing throws, nothing allocates in the hot path (work
+ * buffers come from the context created once by fh_context_create).  All work is enqueued on the
+ * caller's `stream` (a hipStream_t passed as void*); only fh_cg_solve and fh_read_scalars block.
+ *
+ * The reference (AaltoML/free-hunch) is pure Python and has no FFI; each entry point replaces the
+ * PyTorch op sequence cited next to it (paths relative to the reference checkout).  INTEGRATION.md
+ * shows the ctypes binding a reference maintainer would add.
+ *
+ * Layouts (all float64 on the Free Hunch side, matching the reference's float64/complex128 maths):
+ *   image vector  v[planes][S][S]   planes = 3*batch, row-major, n = planes*S*S
+ *   factor base   B[m_cap][d]       column-major: column j is the contiguous slice B + j*d
+ *   small matrix  M[m][ld]          row-major, ld >= m
+ * A covariance "representation"  X = diag(D) + diag(r) B M B^T diag(r)  is the real-arithmetic form of
+ * the reference's  diag + U U^T - V V^T  (complex128 U,V, plain transposes); see DESIGN.md.
+ */
+#ifndef FH_HIP_H
+#define FH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_EINVAL (-1) /* bad argument (null pointer, size out of range) */
+#define FH_ESIZE (-2)  /* size not supported by this build (e.g. m > FH_MAX_COLS) */
+#define FH_MAX_COLS 256
+
+typedef struct fh_context fh_context; /* opaque: DCT bases, reduction scratch, CG state */
+
+/* library / context ---------------------------------------------------------------------------- */
+int fh_version(void);
+/* S = image side (<= 256), planes_max = largest planes count that will be passed, m_cap = column capacity */
+int fh_context_create(fh_context** out, int S, int planes_max, int m_cap);
+int fh_context_destroy(fh_context* ctx);
+
+/* 2-D orthonormal DCT-II (inverse = 0) / DCT-III (inverse = 1) over the last two axes of
+ * in[planes][S][S].  Replaces torch_dct.dct_2d / idct_2d(norm='ortho'),
+ * conditioning_utils/online_update_bfgs.py:351-374.  in may equal out. */
+int fh_dct2d(fh_context* ctx, const double* in, double* out, int planes, int inverse, void* stream);
+
+/* out = D.*z + r.*(B (M (B^T (r.*z))))   - one covariance/Hessian apply.
+ * Replaces CovarianceHessianBFGS._denoiser_cov_vector_dot (and the three sibling *_vector_dot),
+ * online_update_bfgs.py:194-231.  m may be 0 (then B, r, M may be null). */
+int fh_rep_apply(fh_context* ctx, const double* D, const double* r, const double* B, const double* M,
+                 int ldm, const double* z, double* out, int64_t d, int m, void* stream);
+
+/* Woodbury step of online_update_bfgs.py:87-119 in real form, one pass over B:
+ *   Dx      <- Dx + shift                (the time update's diagonal increment, :166 / :172)
+ *   Dy      <- 1 / Dx
+ *   ry      <- rx / Dx
+ *   G[a][b] <- sum_i B[a][i] B[b][i] rx[i]^2 / Dx[i]      (m x m, ld = ldg, device)
+ * The caller finishes with the m x m algebra  My = -Mx (I + G Mx)^-1  (host, float64). */
+int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,
+                  double* ry, double* G, int ldg, int64_t d, int m, void* stream);
+
+/* BFGS "space" update vector work, online_update_bfgs.py:262-304.  Inputs are DCT-domain vectors.
+ *   fh_space_prep:   de <- s2 * dm ;  scal[0] <- dx.de
+ *   fh_dot:          scal[slot] <- a.b
+ *   fh_space_commit: append columns (de, cdx) to both factor bases (divided by the rep's row scale),
+ *                    or fold them into Dc when project != 0; then Dh <- (Dc/s2 - 1)/s2.
+ *                    gamma = 1/(dx.de), q = dx.(C dx) come back from the host. */
+int fh_space_prep(fh_context* ctx, const double* dm, double s2, const double* dx, double* de, double* scal,
+                  int64_t d, void* stream);
+int fh_dot(fh_context* ctx, const double* a, const double* b, double* scal, int slot, int64_t d, void* stream);
+int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double gamma, double q, double s2,
+                    double* Dc, const double* rc, double* Bc_col0, double* Bc_col1, double* Dh, const double* rh,
+                    double* Bh_col0, double* Bh_col1, int project, int64_t d, void* stream);
+
+/* out = alpha*a + beta*b (b may be null when beta == 0); the few remaining elementwise steps of the
+ * time update (mean' = x + sigma'^2 score', online_update_bfgs.py:178-180). */
+int fh_axpby(double alpha, const double* a, double beta, const double* b, double* out, int64_t n, void* stream);
+/* blocking copy of k doubles from device scratch to host (one stream sync) */
+int fh_read_scalars(const double* scal, double* out_host, int k, void* stream);
+
+/* measurement operators, measurement_utils/measurements.py:87-246 + utils_sisr.py:44-96 ----------
+ * Circular 2-D convolution with a sparse tap list (the PSF non-zeros, centre at kernel_size/2):
+ *   adjoint = 0:  out[p][i][j] = sum_t w[t] * in[p][(i*stride - dy[t]) mod S][(j*stride - dx[t]) mod S]
+ *                 (out is [planes][S/stride][S/stride]; stride 4 = blur + decimate of the SR solver)
+ *   adjoint = 1:  out[p][i][j] = sum_t w[t] * up(in)[(i + dy[t]) mod S][(j + dx[t]) mod S]
+ *                 (in is [planes][S/stride][S/stride], zero-inserted on the fly)
+ * halo = max(|dy|, |dx|) over the taps (<= 32).
+ * Equals ifft2(FB * fft2(x)).real / ifft2(conj(FB) * fft2(x)).real of the reference. */
+int fh_conv_circ(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
+                 const double* w, int ntaps, int halo, int planes, int stride, int adjoint, void* stream);
+
+/* the linear solve of conditioning_mechanisms.py:384-419 / 489-527 / 641-675 ------------------------ */
+typedef struct fh_problem {
+  int32_t op;            /* 0 inpainting, 1 blur (gaussian/motion), 2 super-resolution */
+  int32_t use_dct;       /* 1: covariance lives in the DCT basis (CovarianceHessianBFGSDCT) */
+  int32_t planes;        /* 3 * batch(=1) */
+  int32_t stride;        /* SR scale factor, else 1 */
+  int32_t ntaps;
+  int32_t m;             /* factor columns in use */
+  int32_t ldm;
+  int32_t halo;          /* max(|dy|,|dx|) over the taps */
+  int64_t d;             /* planes*S*S */
+  double sigma_y2;       /* measurement-noise variance after the reference's clips */
+  const int32_t* tap_dy; /* [ntaps] */
+  const int32_t* tap_dx;
+  const double* tap_w;
+  const double* mask;    /* [d] 0/1 (inpainting) */
+  const double* D;       /* covariance rep: diag, row scale, base, inner matrix */
+  const double* r;
+  const double* B;
+  const double* M;
+} fh_problem;
+
+typedef struct fh_cg_info {
+  int32_t niter;
+  int32_t optimal;
+  double residual_norm;
+  double b_norm;
+} fh_cg_info;
+
+/* y -> A_mm(u) = sigma_y2*u + A C A^T u   (one application; exposed for tests) */
+int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, void* stream);
+/* conditioning_utils/cg.py:118-292 with M = I, x0 = b: solves A_mm x = b, same stopping rule
+ * (||r|| <= max(rtol*||b||, atol) -> optimal; pAp <= 1e-16 -> break; maxiter).  Blocks. */
+int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
+                int maxiter, fh_cg_info* info_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FH_HIP_H */

@@ -1,0 +1,312 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on seeded inputs and against the golden
+vectors generated from the reference.  Tolerances are stated per test; discrete outcomes (CG iteration counts,
+branch decisions, factor counts) are asserted exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a):
+    if isinstance(a, torch.Tensor):
+        return a.detach().cpu()
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxabs(a, b):
+    return float((T(a).double() - T(b).double()).abs().max())
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------- DCT (a8 wrapper)
+@pytest.mark.parametrize("S", [16, 64, 256])
+def test_dct_matches_scipy_and_roundtrips(dev, S):
+    import scipy.fft
+    from free_hunch_amd import _lib
+    ctx = _lib.Context.get(S, 3, 256)
+    x = inputs.randn((3, S, S), 7 + S)
+    X = ctx.dct2d(x.to(dev))
+    ref = scipy.fft.dctn(x.numpy(), type=2, norm="ortho", axes=(-2, -1))
+    assert maxabs(X, ref) < 1e-12 * max(1.0, np.abs(ref).max())
+    back = ctx.dct2d(X, inverse=True)
+    assert maxabs(back, x) < 1e-12
+    # orthonormality: energy is preserved
+    assert abs(float((X ** 2).sum()) - float((x ** 2).sum())) < 1e-9 * float((x ** 2).sum())
+    # in-place
+    y = x.to(dev).clone()
+    ctx.dct2d(y, out=y)
+    assert maxabs(y, ref) < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- covariance object (a7-a10)
+def _mk_pair(meta, tmp, dev):
+    from oracle import fh_oracle as fo
+    from free_hunch_amd import covariance as hc
+    shape = meta["shape"]
+    d = int(np.prod(shape[1:]))
+    kw = dict(max_vector_count=meta["kw"].get("max_vector_count"),
+              project_to_diagonal=meta["kw"].get("project_to_diagonal", False))
+    orc = fo.make_covariance(meta["kind"], tmp, meta["sigma0"] ** 2, d, **kw)
+    if meta["kind"] == "identity":
+        hip = hc.CovarianceHessianBFGS(1, meta["sigma0"] ** 2, d, device=dev, **kw)
+    else:
+        hip = hc.CovarianceHessianBFGSDCT(tmp, meta["sigma0"] ** 2, d, device=dev,
+                                          use_precalculated_info=(meta["kind"] == "dct_diagonal"), **kw)
+    return orc, hip
+
+
+CASES = [
+    dict(kind="identity", shape=(1, 3, 4, 4), kw={}, sigma0=80.0, n=5, neg=2, only_cov=False),
+    dict(kind="identity", shape=(1, 3, 4, 4), kw={"project_to_diagonal": True}, sigma0=80.0, n=4, neg=None, only_cov=False),
+    dict(kind="identity", shape=(1, 3, 4, 4), kw={"max_vector_count": 0}, sigma0=80.0, n=3, neg=None, only_cov=False),
+    dict(kind="dct_diagonal", shape=(1, 3, 16, 16), kw={}, sigma0=80.0, n=6, neg=3, only_cov=False),
+    dict(kind="dct_diagonal_noinfo", shape=(1, 3, 16, 16), kw={}, sigma0=80.0, n=4, neg=None, only_cov=False),
+    dict(kind="dct_diagonal", shape=(1, 3, 16, 16), kw={}, sigma0=80.0, n=4, neg=None, only_cov=True),
+    dict(kind="dct_diagonal", shape=(1, 3, 64, 64), kw={}, sigma0=80.0, n=20, neg=5, only_cov=False),
+]
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_covariance_vs_oracle(dev, gold, tmp_path, ci):
+    """Scripted time/space updates: predicted means, scores, cov-applies and (small d) all four dense matrices.
+    Tolerance 1e-8 relative: float64 on both sides, different (real vs complex-sqrtm) factorisations."""
+    meta = CASES[ci]
+    S = meta["shape"][-1]
+    dv = T(gold("covariance")["dct_variance16"]) if S == 16 else T(gold("solver")["dct_variance64"])
+    torch.save(dv, tmp_path / "dct_variance.pt")
+    orc, hip = _mk_pair(meta, str(tmp_path), dev)
+    steps = inputs.script(900 + ci, meta["shape"], meta["n"], meta["sigma0"], meta["neg"])
+    probe = inputs.randn(meta["shape"], 950 + ci)
+    tol = 1e-8
+    for si, (what, a) in enumerate(steps):
+        if what == "time":
+            mo, so = orc.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"], only_covariance=meta["only_cov"])
+            mh, sh = hip.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev),
+                                          only_covariance=meta["only_cov"])
+            sc = max(1.0, float(mo.abs().max()))
+            assert maxabs(mh, mo) < tol * sc, (si, "mean")
+            assert maxabs(sh, so) < tol * sc, (si, "score")
+        else:
+            if meta["only_cov"]:
+                continue
+            orc.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+            hip.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+        assert hip.k == orc.k
+        ro = orc.denoiser_cov_vector_dot(probe)
+        rh = hip.denoiser_cov_vector_dot(probe.to(dev))
+        assert maxabs(rh, ro) < tol * max(1.0, float(ro.abs().max())), (si, "apply")
+        if S == 4:
+            for nm, a_, b_ in zip("C Ci H Hi".split(), hip.get_dense_matrices(), orc.dense()):
+                b_ = b_.real
+                if not (meta["kind"] == "identity"):
+                    continue
+                assert maxabs(a_, b_) < 1e-7 * max(1.0, float(b_.abs().max())), (si, nm)
+
+
+def test_covariance_vs_reference_golden(dev, gold, tmp_path):
+    """The dct16 case of covariance.npz (outputs of the reference class itself)."""
+    from free_hunch_amd import covariance as hc
+    g = gold("covariance")
+    torch.save(T(g["dct_variance16"]), tmp_path / "dct_variance.pt")
+    for tag in ("dct16", "dct16_noinfo", "dct16_onlycov"):
+        meta = eval(str(g[f"{tag}__meta"]))
+        hip = hc.CovarianceHessianBFGSDCT(str(tmp_path), meta["sigma0"] ** 2, 768, device=dev,
+                                          use_precalculated_info=(meta["kind"] == "dct_diagonal"))
+        steps = inputs.script(meta["script_seed"], meta["shape"], meta["n_steps"], meta["sigma0"], meta["neg"])
+        probe = inputs.randn(meta["shape"], meta["probe_seed"]).to(dev)
+        for si, (what, a) in enumerate(steps):
+            pre = f"{tag}__{si}_"
+            if what == "time":
+                mean, score = hip.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev),
+                                                   only_covariance=meta["only_cov"])
+                sc = max(1.0, float(np.abs(g[pre + "mean"]).max()))
+                assert maxabs(mean, g[pre + "mean"]) < 1e-8 * sc
+                assert maxabs(score, g[pre + "new_score"]) < 1e-8 * sc
+            else:
+                if meta["only_cov"]:
+                    continue
+                hip.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+            assert hip.k == int(g[pre + "k"])
+            ref = g[pre + "apply"]
+            assert maxabs(hip.denoiser_cov_vector_dot(probe), ref) < 1e-8 * max(1.0, float(np.abs(ref).max()))
+
+
+# ---------------------------------------------------------------- operators (a13)
+def _hip_op(name, size, dev, mask=None):
+    from free_hunch_amd.measurements import get_operator
+    kw = dict(name=name, device=dev, sigma_s=0.1, kernel_size=61, intensity=1.0, scale_factor=4,
+              in_shape=(1, 3, size, size),
+              mask_opt={"mask_type": "random", "mask_len_range": (64, 156), "mask_prob_range": (0.6, 0.8),
+                        "image_size": size})
+    if mask is not None:
+        kw["mask"] = mask
+    return get_operator(**kw)
+
+
+@pytest.mark.parametrize("size", [64, 256])
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
+def test_operators_vs_reference_golden(dev, gold, name, size):
+    g = gold("operators")
+    p = f"{name}_{size}_"
+    mask = T(g[p + "mask"]).float().repeat(1, 3, 1, 1) if name == "inpainting" else None
+    op = _hip_op(name, size, dev, mask)
+    x = inputs.smooth_image(size, 5).to(dev)
+    y = op.forward(x.clone(), noiseless=True)
+    yt = inputs.randn(y.shape, 77, torch.float32).to(dev)
+    xt = op.transpose(yt.clone())
+    st = size // 32
+    ysub = y if (size == 64 or name == "super_resolution") else y[..., ::st, ::st]
+    xsub = xt if size == 64 else xt[..., ::st, ::st]
+    assert y.dtype == torch.float32 and xt.dtype == torch.float32
+    assert maxabs(ysub, g[p + "y"]) < 2e-6          # float32 outputs, c64 FFT in the reference
+    assert maxabs(xsub, g[p + "xt"]) < 2e-5
+    assert abs(float((y.double() ** 2).sum()) - float(g[p + "y_sq"])) < 1e-3 * max(1.0, float(g[p + "y_sq"]))
+    assert abs(float((xt.double() ** 2).sum()) - float(g[p + "xt_sq"])) < 1e-4 * max(1.0, float(g[p + "xt_sq"]))
+
+
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution"])
+def test_operator_adjoint_identity_f64(dev, name):
+    """<A x, y> = <x, A^T y> in float64 at 256x256 (size-independent property)."""
+    op = _hip_op(name, 256, dev)
+    x = inputs.randn((1, 3, 256, 256), 1).to(dev)
+    stride = 4 if name == "super_resolution" else 1
+    ax = op._conv(x, stride=stride)
+    y = inputs.randn(tuple(ax.shape), 2).to(dev)
+    aty = op._conv(y, stride=stride, adjoint=True)
+    lhs, rhs = float((ax * y).sum()), float((x * aty).sum())
+    assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
+
+
+# ---------------------------------------------------------------- solver calls (a11-a12)
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
+def test_solver_vs_reference_golden(dev, gold, name, tmp_path):
+    from free_hunch_amd import covariance as hc
+    from free_hunch_amd.conditioning_mechanisms import choose_solver
+    g = gold("solver")
+    size = 64
+    torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
+    p = f"{name}_"
+    mask = T(g[p + "mask"]).float().repeat(1, 3, 1, 1) if name == "inpainting" else None
+    op = _hip_op(name, size, dev, mask)
+    x = inputs.smooth_image(size, 9)
+    y = T(g[p + "y"]).to(dev)
+    cov = hc.CovarianceHessianBFGSDCT(str(tmp_path), 80.0 ** 2, 3 * size * size, device=dev,
+                                      use_precalculated_info=True)
+    steps = inputs.script(int(g["script_seed"]), (1, 3, size, size), 3, 80.0)
+    for si, (what, a) in enumerate(steps):
+        if what == "time":
+            cov.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev))
+        else:
+            cov.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+        x0_mean = (x + 0.05 * inputs.randn(x.shape, 600 + si, torch.float32)).to(F64).to(dev)
+        for lab in ("hi", "lo"):
+            q = f"{p}{si}_{lab}_"
+            info = []
+            mat = choose_solver(name, op, y, x0_mean, None, cov, "customcuda", 1.0, sigma_t=float(g[q + "sigma_t"]),
+                                info_out=info)
+            assert info[0]["niter"] == int(g[q + "niter"]), (q, info[0], int(g[q + "niter"]))
+            assert info[0]["optimal"] == bool(g[q + "optimal"])
+            ref = T(g[q + "mat_sub"])
+            assert maxabs(mat[..., ::2, ::2], ref) < 1e-5 * max(1.0, float(ref.abs().max())), q
+
+
+def test_cg_full_size_residual_property(dev, tmp_path):
+    """At 256x256 with m = 32 columns: the returned solution satisfies the stopping rule it reports
+    (||b - A_mm x|| <= rtol ||b||), checked with an independent fh_amm application."""
+    import ctypes as C
+    from free_hunch_amd import _lib, covariance as hc
+    from free_hunch_amd.conditioning_mechanisms import _problem, _sigma_y2
+    S, d = 256, 3 * 256 * 256
+    dv = torch.load(os.path.join(ROOT, "free-hunch_amd", "data", "dct_variance.pt"), weights_only=True)
+    torch.save(dv, tmp_path / "dct_variance.pt")
+    cov = hc.CovarianceHessianBFGSDCT(str(tmp_path), 80.0 ** 2, d, device=dev, use_precalculated_info=True)
+    steps = inputs.script(4242, (1, 3, S, S), 16, 80.0)
+    for what, a in steps:
+        if what == "time":
+            cov.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev))
+        else:
+            cov.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+    assert cov.famC.m == 32
+    op = _hip_op("gaussian_blur", S, dev)
+    prob, keep = _problem(op, cov, _sigma_y2(op))
+    b = inputs.randn((1, 3, S, S), 5).to(dev).contiguous()
+    sol = torch.empty_like(b)
+    info = _lib.FhCgInfo()
+    ctx = cov.ctx
+    rtol = 1e-6
+    _lib.check(ctx.lib.fh_cg_solve(ctx.h, C.byref(prob), b.data_ptr(), sol.data_ptr(), rtol, 0.0, 5000, C.byref(info),
+                                   _lib.stream()), "cg")
+    assert info.optimal == 1 and 1 <= info.niter < 5000
+    ax = torch.empty_like(b)
+    _lib.check(ctx.lib.fh_amm(ctx.h, C.byref(prob), sol.data_ptr(), ax.data_ptr(), _lib.stream()), "amm")
+    res = float((b - ax).norm())
+    assert res <= 1.05 * rtol * float(b.norm())
+    assert abs(res - info.residual_norm) < 1e-3 * rtol * float(b.norm())
+    # symmetry of A_mm (needed by CG): <u, A v> = <A u, v>
+    u = inputs.randn((1, 3, S, S), 6).to(dev).contiguous()
+    au = torch.empty_like(u)
+    _lib.check(ctx.lib.fh_amm(ctx.h, C.byref(prob), u.data_ptr(), au.data_ptr(), _lib.stream()), "amm")
+    l, r = float((u * ax).sum()), float((au * sol).sum())
+    assert abs(l - r) < 1e-9 * max(abs(l), 1.0)
+
+
+# ---------------------------------------------------------------- whole trajectories (a1, a6)
+def _hip_net(gold_traj, dev, backend):
+    from free_hunch_amd import unet as hu
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+    cfg = hu.UNetConfig(**{k: getattr(inputs.SMALL_A, k) for k in
+                           ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma",
+                            "attention_resolutions", "num_heads", "num_head_channels", "use_scale_shift_norm",
+                            "resblock_updown", "use_new_attention_order")})
+    model = hu.UNetModel(cfg, backend=backend)
+    model.load_state_dict(hu.seeded_state(cfg, int(gold_traj["unet_seed"])))
+    model = model.to(dev).eval()
+    return iDDPMLinearPrecond(model, cfg.image_size, 3).to(dev)
+
+
+TRAJ = ["gb_heun10", "mb_heun10", "sr_heun10", "ip_euler20", "gb_heun10_nospace", "gb_heun10_readme",
+        "gb_heun10_identity", "gb_heun30"]
+
+
+@pytest.mark.parametrize("tag", TRAJ)
+def test_trajectory_vs_reference_golden(dev, gold, tag, tmp_path):
+    """Full sampler runs at 64x64 against trajectories recorded from the reference's own conditional_sampler:
+    k and the vjp/cov branch per call must match exactly, CG iteration counts exactly, final image within the
+    north-star tolerance 1e-3 max-abs."""
+    from free_hunch_amd.sampler import conditional_sampler
+    g = gold("trajectories")
+    p = tag + "__"
+    torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
+    over = eval(str(g[p + "over"]))
+    opname, solver, nsteps = str(g[p + "op"]), str(g[p + "solver"]), int(g[p + "num_steps"])
+    s_img, s_noise = (int(v) for v in g[p + "seeds"])
+    net = _hip_net(g, dev, os.environ.get("FH_UNET_BACKEND", "hip"))
+    mask = T(g[p + "mask"]).float().repeat(1, 3, 1, 1) if opname == "inpainting" else None
+    op = _hip_op(opname, 64, dev, mask)
+    noise = inputs.randn((1, 3, 64, 64), s_noise, torch.float32).to(dev)
+    y = T(g[p + "y"]).to(dev)
+    base = dict(conditioning_mechanism="online_covariance", cond_scaling=1.0, clip_x0_mean=False,
+                max_vector_count=100000, dataset_path=str(tmp_path), image_base_covariance="dct_diagonal",
+                denoiser_mean_error_threshold=0.2, use_analytical_score_time_update=True, project_to_diagonal=False,
+                space_step_update_threshold=10.0, space_step_update_lower_threshold=1.0, max_rtol=1.0,
+                do_space_updates=True)
+    x, _, _ = conditional_sampler(net, noise, None, None, num_steps=nsteps, sigma_min=0.002, sigma_max=80, rho=7,
+                                  solver=solver, measurement=y, operator=op, **{**base, **over})
+    tr = conditional_sampler.last_mechanism.trace
+    assert [t["k"] for t in tr] == list(g[p + "k"])
+    assert [int(t["branch"] == "cov") for t in tr] == list(g[p + "branch_cov"])
+    assert np.array_equal([t["sigma"] for t in tr], g[p + "sigma"])
+    assert [t["niter"] for t in tr] == list(g[p + "niter"])
+    assert maxabs(x, g[p + "x_final"]) < 1e-3
