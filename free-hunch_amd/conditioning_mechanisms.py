@@ -223,6 +223,10 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             rec["branch"] = "vjp"
         x_0_mean_new = m_det + p_y_xt_grad * sig2
         rec["k"], rec["sigma"] = cm.k, s
+        if os.environ.get("FH_TRACE_SUMS"):  # debugging aid: costs a device sync per call
+            rec["out_sum"] = float(x_0_mean_new.double().sum())
+            rec["mean_sum"] = float(m_det.double().sum())
+            rec["mat_sum"] = float(mat.double().sum())
         self.trace.append(rec)
         self.sigmas.append(s)
         self.xs.append(x_det)
