@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the Free Hunch hot path on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--arch ffhq|imagenet] [--operator NAME]
+
+One "step" = one batch of B independent 256x256 images, each taken through the full FH-Heun sampler
+(num_steps = 30 -> 59 guidance calls = 59 UNet forwards + 59 input-VJPs + 59 CG solves + covariance updates).
+Workload at N = 1: BASELINE.json configs[1] (FFHQ-256 architecture, gaussian_blur, low-rank covariance,
+num_steps = 30, batch = 8).  N > 1: one process per GPU (torch.distributed / RCCL), every rank runs its own batch
+(weak scaling), outputs are exchanged with ONE all_gather per step inside the timed region.
+Inputs are synthetic (seeded images and weights; there are no checkpoints or datasets offline).
+
+Besides the headline line the JSON carries
+  roofline      cov-apply (fh_rep_apply at d = 196608, m = 32) timed with events on the launch stream,
+                algorithmic bytes / time against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (a port of the reference path) timed on the host cores on a bounded sample of the
+                same workload (the first guidance calls of one image), extrapolated to images/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def smooth_images(n, size, seed):
+    g = np.random.default_rng(seed)
+    f = g.standard_normal((n, 3, size, size))
+    fy, fx = np.fft.fftfreq(size)[:, None], np.fft.fftfreq(size)[None, :]
+    img = np.real(np.fft.ifft2(np.fft.fft2(f) / (1 + 40 * np.sqrt(fy ** 2 + fx ** 2)) ** 1.5))
+    img = img / np.abs(img).max(axis=(1, 2, 3), keepdims=True)
+    return torch.from_numpy(((img + 1) * 127.5).clip(0, 255).astype(np.uint8))
+
+
+def fh_kwargs(data_dir, solver):
+    return dict(conditioning_mechanism="online_covariance", cond_scaling=1.0, clip_x0_mean=False,
+                max_vector_count=100000, dataset_path=data_dir, image_base_covariance="dct_diagonal",
+                denoiser_mean_error_threshold=0.2, use_analytical_score_time_update=True, project_to_diagonal=False,
+                space_step_update_threshold=10.0, space_step_update_lower_threshold=1.0, max_rtol=1.0,
+                do_space_updates=True, solver_type="customcuda")
+
+
+def build_net(arch, device, backend):
+    from free_hunch_amd import unet as hu
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+    cfg = {"ffhq": hu.FFHQ256, "imagenet": hu.IMAGENET256}[arch]
+    model = hu.UNetModel(cfg, backend=backend)
+    model.load_state_dict(hu.seeded_state(cfg, 0))
+    model = model.to(device).eval()
+    return iDDPMLinearPrecond(model, cfg.image_size, 3).to(device), cfg
+
+
+def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir):
+    """B independent images through the sampler; returns uint8 [B,3,S,S] on the device."""
+    from free_hunch_amd.measurements import get_operator
+    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler
+    enc = StandardRGBEncoder()
+    S = images_u8.shape[-1]
+    outs = []
+    for img, seed in zip(images_u8, seeds):
+        np.random.seed(int(seed))
+        torch.manual_seed(int(seed))
+        op = get_operator(name=operator_name, device=device, sigma_s=0.1, kernel_size=61, intensity=1.0,
+                          scale_factor=4, in_shape=(1, 3, S, S),
+                          mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
+                                    "mask_prob_range": (0.6, 0.8), "image_size": S})
+        x0 = enc.encode(img[None].to(device))
+        noise = torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(int(seed)), dtype=torch.float32)
+        x, _, _ = conditional_sampler(net, noise.to(device), x0, None, num_steps=num_steps, sigma_min=0.002,
+                                      sigma_max=80, rho=7, solver=solver, operator=op, **fh_kwargs(data_dir, solver))
+        outs.append(enc.decode(x))
+    return torch.cat(outs, 0)
+
+
+def roofline_cov_apply(device, m=32, iters=200):
+    """fh_rep_apply at the headline point d = 196608, m = 32 (float64 base), events on the stream."""
+    from free_hunch_amd import _lib
+    S, d = 256, 3 * 256 * 256
+    ctx = _lib.Context.get(S, 3, 256)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    B = torch.randn(m, d, generator=g, dtype=torch.float64).to(device)
+    D = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device)
+    r = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device)
+    M = torch.randn(64, 64, generator=g, dtype=torch.float64).to(device)
+    z = torch.randn(d, generator=g, dtype=torch.float64).to(device)
+    out = torch.empty_like(z)
+    for _ in range(10):
+        ctx.rep_apply(D, r, B, M, z, out, m)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ctx.rep_apply(D, r, B, M, z, out, m)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    algo_bytes = 8 * d * m + 8 * d * 4  # base once + D, r, z read + out written (float64)
+    achieved = algo_bytes / sec / 1e9
+    return {"bound": "hbm", "kernel": "fh_rep_apply = k_rep_dots + k_rep_coef + k_rep_apply2 (d=196608, m=32, f64)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
+
+
+def cpu_baseline(arch, operator_name, num_steps, data_dir, calls=5):
+    """The oracle (port of the reference path) on the host cores: `calls` guidance calls of one image, extrapolated."""
+    from oracle import fh_oracle as fo, unet_oracle as uo
+    import scipy.io
+    cfg = {"ffhq": uo.FFHQ256, "imagenet": uo.IMAGENET256}[arch]
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    net = fo.LinearPrecond(uo.OracleUNet(cfg, uo.seeded_state(cfg, 0)))
+    S = 256
+    kd = os.path.join(ROOT, "free-hunch_amd", "data", "kernels")
+    kernel = np.load(os.path.join(kd, "gaussian_ks61_std3.0.npy"))
+    op = fo.OracleOperator("gaussian_blur", (1, 3, S, S), 0.1, kernel=kernel)
+    img = smooth_images(1, S, 1234)[0]
+    x0 = fo.encode_rgb(img[None])
+    g = torch.Generator().manual_seed(0)
+    y = op.forward(x0, noise=torch.randn(x0.shape, generator=g))
+    noise = torch.randn((1, 3, S, S), generator=g, dtype=torch.float32)
+    n_calls = 2 * num_steps - 1
+
+    class Stop(Exception):
+        pass
+
+    times = []
+
+    def fac(op_, v0, d):
+        mech = fo.OracleFreeHunch(1.0, op_, False, v0, d, image_base_covariance="dct_diagonal", data_dir=data_dir)
+        orig = mech.__call__
+
+        class Timed:
+            def __call__(self, *a):
+                t0 = time.perf_counter()
+                out = mech(*a)
+                times.append(time.perf_counter() - t0)
+                if len(times) >= calls:
+                    raise Stop()
+                return out
+        return Timed()
+
+    t0 = time.perf_counter()
+    try:
+        fo.conditional_sampler(net, noise, y, op, num_steps=num_steps, solver="heun", mechanism_factory=fac)
+    except Stop:
+        pass
+    wall = time.perf_counter() - t0
+    per_call = float(np.mean(times))
+    return {"value": round(1.0 / (per_call * n_calls), 6), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"first {len(times)} of {n_calls} guidance calls of one image ({wall:.1f} s), mean call "
+                      f"{per_call:.2f} s, extrapolated x{n_calls}; high-sigma calls have the longest CG solves, so "
+                      f"this slightly under-states the CPU rate"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--arch", default="ffhq", choices=["ffhq", "imagenet"])
+    ap.add_argument("--operator", default="gaussian_blur")
+    ap.add_argument("--num-steps", type=int, default=30)
+    ap.add_argument("--solver", default="heun")
+    ap.add_argument("--unet-backend", default=os.environ.get("FH_UNET_BACKEND", "hip"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-calls", type=int, default=5)
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    data_dir = os.path.join(ROOT, "free-hunch_amd", "data")
+    net, cfg = build_net(a.arch, device, a.unet_backend)
+    images = smooth_images(a.batch, 256, 1234 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        seeds = [(i * world + rank) * a.batch + j for j in range(a.batch)]
+        out = run_batch(net, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir)
+        if world > 1:  # the path's one exchange: gather the finished uint8 images
+            bufs = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(bufs, out)
+        return out
+
+    for i in range(a.warmup):
+        step(-1 - i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        total_images = a.steps * a.batch * world
+        line = {
+            "metric": f"images/sec (256x256, num_steps={a.num_steps}, FH-{a.solver.capitalize()})",
+            "value": round(total_images / elapsed, 5), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 UNet + f64 covariance/CG", "data": "synthetic",
+            "config": {"workload": f"{a.arch.upper()}-256 arch, {a.operator}, FH low-rank covariance (dct_diagonal), "
+                                   f"num_steps={a.num_steps} {a.solver}, batch={a.batch} per GPU",
+                       "images_per_step": a.batch * world, "unet_backend": a.unet_backend,
+                       "net_calls_per_image": 2 * a.num_steps - 1 if a.solver == "heun" else a.num_steps},
+        }
+        line["roofline"] = roofline_cov_apply(device)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.arch, a.operator, a.num_steps, data_dir, a.cpu_calls)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

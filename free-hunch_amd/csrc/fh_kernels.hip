@@ -19,63 +19,72 @@ using namespace fh;
   if ((done) != nullptr && *(done) != 0) return
 
 // ------------------------------------------------------------------------------------------------
-// Small float64 GEMM used by the DCT passes:  C = A * op(B),  A [M][K] (lda), C [M][N] (ldc),
-// BT ? B [N][K] : B [K][N]  (ldb).  32x32 tile, BK = 16, 2x2 outputs per thread.
+// float64 GEMM for the two DCT passes on the matrix cores (v_mfma_f64_16x16x4_f64):
+//   C = A * op(B),  A [M][K] (lda), C [M][N] (ldc),  BT ? B [N][K] : B [K][N]  (ldb).
+// 32x32 output tile per workgroup, one 16x16 MFMA tile per wave, K staged through LDS in chunks of
+// 32 with both operands k-contiguous (row stride 34 doubles: conflict-free ds_read_b64 for the
+// A[i=l&15][k=l>>4] / B[k=l>>4][j=l&15] operand maps).  f64 C/D map: col = l&15, row = (l>>4) + 4*reg.
 // ------------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 template <bool BT>
 __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                   int ldc, int64_t sA, int64_t sB, int64_t sC,
                                                   const int* __restrict__ done) {
   DONE_GUARD(done);
-  constexpr int BM = 32, BN = 32, BK = 16;
-  __shared__ double As[BK][BM + 2];
-  __shared__ double Bs[BK][BN + 2];
+  constexpr int BM = 32, BN = 32, BK = 32, LD = BK + 2;
+  __shared__ double As[BM][LD];
+  __shared__ double Bs[BN][LD];
   A += sA * blockIdx.z;
   B += sB * blockIdx.z;
   C += sC * blockIdx.z;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+  const int li = lane & 15, lk = lane >> 4;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  const int srow = tid >> 3, sseg = (tid & 7) * 4;  // staging: 32 rows x 8 segments of 4 doubles
   for (int k0 = 0; k0 < K; k0 += BK) {
+    {
+      const int gm = m0 + srow;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int idx = tid + 256 * e;
-      {
-        const int row = idx / BK, kk = idx % BK;
-        const int gm = m0 + row, gk = k0 + kk;
-        As[kk][row] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
+      for (int e = 0; e < 4; ++e) {
+        const int gk = k0 + sseg + e;
+        As[srow][sseg + e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
       }
-      if (BT) {
-        const int row = idx / BK, kk = idx % BK;
-        const int gn = n0 + row, gk = k0 + kk;
-        Bs[kk][row] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
-      } else {
-        const int kk = idx / BN, col = idx % BN;
-        const int gn = n0 + col, gk = k0 + kk;
-        Bs[kk][col] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
+    }
+    if (BT) {
+      const int gn = n0 + srow;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gk = k0 + sseg + e;
+        Bs[srow][sseg + e] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+      }
+    } else {
+      const int gk = k0 + srow;  // srow indexes k here, sseg the n segment
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gn = n0 + sseg + e;
+        Bs[sseg + e][srow] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < BK; ++kk) {
-      const double a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
-      const double b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
-      c00 = fma(a0, b0, c00);
-      c01 = fma(a0, b1, c01);
-      c10 = fma(a1, b0, c10);
-      c11 = fma(a1, b1, c11);
+    for (int kk = 0; kk < BK; kk += 4) {
+      const double a = As[wm + li][kk + lk];
+      const double b = Bs[wn + li][kk + lk];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
   }
-  const int gm = m0 + ty * 2, gn = n0 + tx * 2;
-  if (gm < M) {
-    if (gn < N) C[(int64_t)gm * ldc + gn] = c00;
-    if (gn + 1 < N) C[(int64_t)gm * ldc + gn + 1] = c01;
-  }
-  if (gm + 1 < M) {
-    if (gn < N) C[(int64_t)(gm + 1) * ldc + gn] = c10;
-    if (gn + 1 < N) C[(int64_t)(gm + 1) * ldc + gn + 1] = c11;
+  const int gn = n0 + wn + li;
+  if (gn < N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gm = m0 + wm + lk + 4 * r;
+      if (gm < M) C[(int64_t)gm * ldc + gn] = acc[r];
+    }
   }
 }
 
@@ -152,19 +161,45 @@ __global__ __launch_bounds__(256) void k_rep_coef(const double* __restrict__ par
                                                   const double* __restrict__ M, int ldm, int m,
                                                   double* __restrict__ coef, const int* __restrict__ done) {
   DONE_GUARD(done);
+  // one workgroup; columns are processed 32 at a time by 8 row-groups of 32 threads so that the
+  // nblocks x m partials are read with 8 x 32 independent, coalesced loads in flight
   __shared__ double t[FH_MAX_COLS];
-  const int j = threadIdx.x;
-  if (j < m) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * FH_MAX_COLS + j];
-    t[j] = s;
+  __shared__ double red[8][33];
+  const int tid = threadIdx.x, jj = tid & 31, rg = tid >> 5;
+  for (int j0 = 0; j0 < m; j0 += 32) {
+    const int j = j0 + jj;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (j < m) {
+      int b = rg;
+      for (; b + 24 < nblocks; b += 32) {
+        s0 += partial[(int64_t)b * FH_MAX_COLS + j];
+        s1 += partial[(int64_t)(b + 8) * FH_MAX_COLS + j];
+        s2 += partial[(int64_t)(b + 16) * FH_MAX_COLS + j];
+        s3 += partial[(int64_t)(b + 24) * FH_MAX_COLS + j];
+      }
+      for (; b < nblocks; b += 8) s0 += partial[(int64_t)b * FH_MAX_COLS + j];
+    }
+    red[rg][jj] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && j < m) {
+      double s = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += red[g][jj];
+      t[j] = s;
+      coef[FH_MAX_COLS + j] = s;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (j < m) {
+  // c = M t : 8 threads per output row, shuffle-reduced
+  for (int r0 = 0; r0 < m; r0 += 32) {
+    const int row = r0 + (tid >> 3), part = tid & 7;
     double s = 0.0;
-    for (int l = 0; l < m; ++l) s = fma(M[(int64_t)j * ldm + l], t[l], s);
-    coef[j] = s;
-    coef[FH_MAX_COLS + j] = t[j];
+    if (row < m)
+      for (int l = part; l < m; l += 8) s = fma(M[(int64_t)row * ldm + l], t[l], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (row < m && part == 0) coef[row] = s;
   }
 }
 
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, co
   if (rx != nullptr) ry[i] = rx[i] / v;
 }
 
-constexpr int kGramRowBlocks = 192;
+constexpr int kGramRowBlocks = 128;
 constexpr int kGT = 64;  // Gram tile edge and row-chunk length
 
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, const double* __restrict__ rx,
@@ -302,7 +337,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, cons
 
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ gpartial, int nrb, int ntiles, int m,
                                                      double* __restrict__ G, int ldg) {
-  // one workgroup per tile pair; 4096 outputs, 16 per thread
+  // grid (tile pairs, 16): each thread owns one of the 4096 tile outputs and sums the nrb row-block partials
   int ta = 0, tb = 0, p = blockIdx.x;
   for (ta = 0; ta < ntiles; ++ta) {
     const int cnt = ntiles - ta;
@@ -313,14 +348,21 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     p -= cnt;
   }
   const double* src = gpartial + (int64_t)blockIdx.x * nrb * (kGT * kGT);
-  for (int o = threadIdx.x; o < kGT * kGT; o += 256) {
-    double s = 0.0;
-    for (int b = 0; b < nrb; ++b) s += src[(int64_t)b * (kGT * kGT) + o];
-    const int a = ta * kGT + o / kGT, c = tb * kGT + o % kGT;
-    if (a < m && c < m) {
-      G[(int64_t)a * ldg + c] = s;
-      if (ta != tb) G[(int64_t)c * ldg + a] = s;
-    }
+  const int o = blockIdx.y * 256 + threadIdx.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = 0;
+  for (; b + 3 < nrb; b += 4) {
+    s0 += src[(int64_t)b * (kGT * kGT) + o];
+    s1 += src[(int64_t)(b + 1) * (kGT * kGT) + o];
+    s2 += src[(int64_t)(b + 2) * (kGT * kGT) + o];
+    s3 += src[(int64_t)(b + 3) * (kGT * kGT) + o];
+  }
+  for (; b < nrb; ++b) s0 += src[(int64_t)b * (kGT * kGT) + o];
+  const double s = (s0 + s1) + (s2 + s3);
+  const int a = ta * kGT + o / kGT, c = tb * kGT + o % kGT;
+  if (a < m && c < m) {
+    G[(int64_t)a * ldg + c] = s;
+    if (ta != tb) G[(int64_t)c * ldg + a] = s;
   }
 }
 
@@ -759,7 +801,7 @@ int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B
     if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems) return FH_ESIZE;
     hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, st, B, rx, (const double*)Dx,
                        ctx->gpartial, d, m, ntiles);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 256), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
                        ntiles, m, G, ldg);
   } else {
     hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);

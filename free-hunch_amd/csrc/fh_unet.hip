@@ -1,0 +1,613 @@
+// UNet kernels for gfx950 (CDNA4): float32, activations NHWC in HBM.
+//
+//  * k_conv_igemm   implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+//                   M = N*Ho*Wo pixels, N = Cout, K = taps*Cin with Cin innermost.  Used for 3x3 / 1x1 forward
+//                   and - with the pre-flipped, transposed weight copy - for the input gradient (dgrad).
+//                   Fused epilogue: + bias[co] (+ residual[pixel][co]).
+//  * k_bgemm        strided batched GEMM (same MFMA core) for attention: QK^T, PV and the four backward products.
+//  * GroupNorm(32) statistics / apply(+scale-shift, +SiLU) / backward, softmax forward / backward,
+//    2x2 average pool and nearest 2x upsample (forward and adjoint), channel concat / split, NCHW<->NHWC.
+//
+// Tiling (wave64): a workgroup of 4 waves owns a (2*MI*32) x (2*NI*32) output tile, each wave MI x NI
+// accumulator tiles of 32x32 (16 VGPRs each).  K advances in chunks of 32 floats staged through LDS with both
+// operands k-contiguous and a row stride of 36 floats, which makes the ds_read_b128 fragment reads
+// conflict-free; one b128 read feeds four MFMAs (k order inside a group of 8 is permuted identically for A
+// and B: lane half h supplies k = 4h + s at step s).  Global loads for chunk c+1 are issued before the MFMAs
+// of chunk c and written to the other LDS buffer afterwards: one barrier per chunk.
+#include "fh_common.h"
+
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kBK = 32;       // K chunk (floats)
+constexpr int kLd = kBK + 4;  // LDS row stride in floats (144 B)
+
+struct ConvArgs {
+  const float* in;    // [N][H][W][Cin]
+  const float* w;     // [Cout][taps][Cin]
+  const float* bias;  // [Cout] or null
+  const float* res;   // [N][Ho][Wo][Cout] or null
+  float* out;         // [N][Ho][Wo][Cout]
+  int N, H, W, Cin, Cout, KH, KW, pad, stride, Ho, Wo;
+};
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  constexpr int BM = 2 * MI * 32, BN = 2 * NI * 32;
+  constexpr int TPR_A = 256 / BM, TPR_B = 256 / BN;    // threads per staged row
+  constexpr int FA = kBK / TPR_A, FB = kBK / TPR_B;    // floats per thread per chunk
+  __shared__ __align__(16) float As[2][BM][kLd];
+  __shared__ __align__(16) float Bs[2][BN][kLd];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * (MI * 32), wn = (wave & 1) * (NI * 32);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int taps = a.KH * a.KW;
+  const int cpt = a.Cin / kBK;  // chunks per tap
+  const int nchunks = taps * cpt;
+
+  // staging coordinates (fixed over the K loop)
+  const int ra = tid / TPR_A, ca = (tid % TPR_A) * FA;
+  const int rb = tid / TPR_B, cb = (tid % TPR_B) * FB;
+  const int64_t pm = m0 + ra;
+  const bool pvalid = pm < M;
+  int pn = 0, pho = 0, pwo = 0;
+  if (pvalid) {
+    pn = (int)(pm / ((int64_t)a.Ho * a.Wo));
+    const int rem = (int)(pm % ((int64_t)a.Ho * a.Wo));
+    pho = rem / a.Wo;
+    pwo = rem % a.Wo;
+  }
+  const int co_b = n0 + rb;
+  const bool bvalid = co_b < a.Cout;
+  const float* wrow = a.w + (int64_t)(bvalid ? co_b : 0) * taps * a.Cin + cb;
+
+  float4 ra_reg[FA / 4], rb_reg[FB / 4];
+
+  auto load_chunk = [&](int c) {
+    const int tap = c / cpt, c0 = (c % cpt) * kBK;
+    const int ky = tap / a.KW, kx = tap % a.KW;
+    const int hi = pho * a.stride + ky - a.pad, wi = pwo * a.stride + kx - a.pad;
+    const bool ok = pvalid && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+    const float* src = a.in + (((int64_t)pn * a.H + (ok ? hi : 0)) * a.W + (ok ? wi : 0)) * a.Cin + c0 + ca;
+#pragma unroll
+    for (int e = 0; e < FA / 4; ++e)
+      ra_reg[e] = ok ? *reinterpret_cast<const float4*>(src + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* wsrc = wrow + (int64_t)tap * a.Cin + c0;
+#pragma unroll
+    for (int e = 0; e < FB / 4; ++e)
+      rb_reg[e] = bvalid ? *reinterpret_cast<const float4*>(wsrc + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < FA / 4; ++e) *reinterpret_cast<float4*>(&As[buf][ra][ca + 4 * e]) = ra_reg[e];
+#pragma unroll
+    for (int e = 0; e < FB / 4; ++e) *reinterpret_cast<float4*>(&Bs[buf][rb][cb + 4 * e]) = rb_reg[e];
+  };
+
+  float16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll
+    for (int g = 0; g < kBK / 8; ++g) {
+      float4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][wm + i * 32 + lr][g * 8 + 4 * lh]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn + j * 32 + lr][g * 8 + 4 * lh]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float av = s == 0 ? af[i].x : s == 1 ? af[i].y : s == 2 ? af[i].z : af[i].w;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const float bv = s == 0 ? bf[j].x : s == 1 ? bf[j].y : s == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn + j * 32 + lr;
+    if (co >= a.Cout) continue;
+    const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (a.res != nullptr) v += a.res[row * a.Cout + co];
+          a.out[row * a.Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched GEMM for attention.  C[b] = alpha * opA(A[b]) * opB(B[b]);  C is [M][N] row-major (ldc).
+//   TA = 0: A stored [M][K] (lda)   TA = 1: A stored [K][M] (lda)
+//   TB = 0: B stored [N][K] (ldb)   TB = 1: B stored [K][N] (ldb)      ("[N][K]" = K-contiguous, as the conv weights)
+// batch index b = blockIdx.z -> (b / inner, b % inner) with two strides per operand so that (image, head) pairs
+// address interleaved qkv channels without copies.  64x64 tile, one 32x32 MFMA tile per wave.
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K, lda, ldb, ldc, inner;
+  int64_t sA0, sA1, sB0, sB1, sC0, sC1;
+  float alpha;
+};
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
+  constexpr int BM = 64, BN = 64;
+  __shared__ __align__(16) float As[BM][kLd];
+  __shared__ __align__(16) float Bs[BN][kLd];
+  const int b0 = blockIdx.z / g.inner, b1 = blockIdx.z % g.inner;
+  const float* A = g.A + b0 * g.sA0 + b1 * g.sA1;
+  const float* B = g.B + b0 * g.sB0 + b1 * g.sB1;
+  float* C = g.C + b0 * g.sC0 + b1 * g.sC1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  float16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += kBK) {
+    // stage 64 x 32 of each operand (2048 floats, 8 per thread)
+    if (TA == 0) {
+      const int row = tid >> 2, col = (tid & 3) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gm = m0 + row, gk = k0 + col + e;
+        As[row][col + e] = (gm < g.M && gk < g.K) ? A[(int64_t)gm * g.lda + gk] : 0.f;
+      }
+    } else {
+      const int kk = tid >> 3, col = (tid & 7) * 8;  // 32 k-rows x 64 m
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gm = m0 + col + e, gk = k0 + kk;
+        As[col + e][kk] = (gm < g.M && gk < g.K) ? A[(int64_t)gk * g.lda + gm] : 0.f;
+      }
+    }
+    if (TB == 0) {
+      const int row = tid >> 2, col = (tid & 3) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gn = n0 + row, gk = k0 + col + e;
+        Bs[row][col + e] = (gn < g.N && gk < g.K) ? B[(int64_t)gn * g.ldb + gk] : 0.f;
+      }
+    } else {
+      const int kk = tid >> 3, col = (tid & 7) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gn = n0 + col + e, gk = k0 + kk;
+        Bs[col + e][kk] = (gn < g.N && gk < g.K) ? B[(int64_t)gk * g.ldb + gn] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int gq = 0; gq < kBK / 8; ++gq) {
+      const float4 af = *reinterpret_cast<const float4*>(&As[wm + lr][gq * 8 + 4 * lh]);
+      const float4 bf = *reinterpret_cast<const float4*>(&Bs[wn + lr][gq * 8 + 4 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn + lr;
+  if (col < g.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < g.M) C[(int64_t)row * g.ldc + col] = g.alpha * acc[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm (32 groups, eps 1e-5) on NHWC.  x [N][P][C], P = H*W, cg = C / 32 channels per group.
+//   k_gn_stats : one workgroup per (n, group); sums in double; writes mean / rstd (float) [N][32][2]
+//   k_gn_apply : y = act( ((x - mean) * rstd * gamma + beta) * (1 + scale[n][c]) + shift[n][c] ),  act = SiLU or id
+//   k_gn_bwd_* : dx given dy (through act, scale/shift, affine and the normalisation)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, float* __restrict__ stats, int P,
+                                                  int C) {
+  __shared__ double red[4];
+  const int n = blockIdx.x / 32, grp = blockIdx.x % 32, cg = C / 32;
+  const float* base = x + (int64_t)n * P * C + grp * cg;
+  const int64_t total = (int64_t)P * cg;
+  double s = 0.0, ss = 0.0;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int64_t p = i / cg;
+    const int c = (int)(i % cg);
+    const float v = base[p * C + c];
+    s += v;
+    ss += (double)v * v;
+  }
+  s = fh::block_sum_256(s, red);
+  ss = fh::block_sum_256(ss, red);
+  if (threadIdx.x == 0) {
+    const double mean = s / total;
+    double var = ss / total - mean * mean;
+    var = var < 0 ? 0 : var;
+    stats[(int64_t)blockIdx.x * 2] = (float)mean;
+    stats[(int64_t)blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  int ss_stride, float* __restrict__ y, int64_t total, int P, int C,
+                                                  int act) {
+  const int cg = C / 32;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((int64_t)P * C));
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ce = c + e;
+      const float* st = stats + ((int64_t)n * 32 + ce / cg) * 2;
+      float t = (v[e] - st[0]) * st[1] * gamma[ce] + beta[ce];
+      if (scale != nullptr) t = t * (1.f + scale[(int64_t)n * ss_stride + ce]) + shift[(int64_t)n * ss_stride + ce];
+      v[e] = act ? silu_f(t) : t;
+    }
+    *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// backward pass 1: per (n, group) sums  a = sum(g),  b = sum(g * xhat)   with g = dL/d(xhat) (after act/scale/affine)
+__global__ __launch_bounds__(256) void k_gn_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int ss_stride, float* __restrict__ sums, int P, int C, int act) {
+  __shared__ double red[4];
+  const int n = blockIdx.x / 32, grp = blockIdx.x % 32, cg = C / 32;
+  const int64_t off = (int64_t)n * P * C + grp * cg;
+  const float mean = stats[(int64_t)blockIdx.x * 2], rstd = stats[(int64_t)blockIdx.x * 2 + 1];
+  const int64_t total = (int64_t)P * cg;
+  double sa = 0.0, sb = 0.0;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int64_t p = i / cg;
+    const int c = grp * cg + (int)(i % cg);
+    const int64_t idx = off + p * C + (c - grp * cg);
+    const float xh = (x[idx] - mean) * rstd;
+    float gsc = 1.f, t = xh * gamma[c] + beta[c];
+    if (scale != nullptr) {
+      gsc = 1.f + scale[(int64_t)n * ss_stride + c];
+      t = t * gsc + shift[(int64_t)n * ss_stride + c];
+    }
+    float g = dy[idx];
+    if (act) {
+      const float sg = 1.f / (1.f + __expf(-t));
+      g *= sg * (1.f + t * (1.f - sg));
+    }
+    g *= gsc * gamma[c];
+    sa += g;
+    sb += (double)g * xh;
+  }
+  sa = fh::block_sum_256(sa, red);
+  sb = fh::block_sum_256(sb, red);
+  if (threadIdx.x == 0) {
+    sums[(int64_t)blockIdx.x * 2] = (float)(sa / total);
+    sums[(int64_t)blockIdx.x * 2 + 1] = (float)(sb / total);
+  }
+}
+
+// backward pass 2: dx = rstd * (g - mean(g) - xhat * mean(g * xhat))  (+ dx_add when accumulate)
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ stats, const float* __restrict__ sums,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int ss_stride, float* __restrict__ dx, int64_t total, int P,
+                                                      int C, int act, int accumulate) {
+  const int cg = C / 32;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((int64_t)P * C));
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    const float4 gv = *reinterpret_cast<const float4*>(dy + i);
+    float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
+    if (accumulate) {
+      const float4 ov = *reinterpret_cast<const float4*>(dx + i);
+      o[0] = ov.x, o[1] = ov.y, o[2] = ov.z, o[3] = ov.w;
+    } else {
+      o[0] = o[1] = o[2] = o[3] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ce = c + e;
+      const int64_t sidx = ((int64_t)n * 32 + ce / cg) * 2;
+      const float mean = stats[sidx], rstd = stats[sidx + 1];
+      const float xh = (xs[e] - mean) * rstd;
+      float gsc = 1.f, t = xh * gamma[ce] + beta[ce];
+      if (scale != nullptr) {
+        gsc = 1.f + scale[(int64_t)n * ss_stride + ce];
+        t = t * gsc + shift[(int64_t)n * ss_stride + ce];
+      }
+      float g = gs[e];
+      if (act) {
+        const float sg = 1.f / (1.f + __expf(-t));
+        g *= sg * (1.f + t * (1.f - sg));
+      }
+      g *= gsc * gamma[ce];
+      o[e] += rstd * (g - sums[sidx] - xh * sums[sidx + 1]);
+    }
+    *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row softmax (rows of length T <= 4096), forward in place and backward  dS = P .* (dP - rowsum(dP .* P))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_softmax_rows(float* __restrict__ s, int T) {
+  __shared__ float redf[4];
+  __shared__ double redd[4];
+  float* row = s + (int64_t)blockIdx.x * T;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < T; i += 256) mx = fmaxf(mx, row[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+  double sum = 0.0;
+  for (int i = threadIdx.x; i < T; i += 256) {
+    const float e = __expf(row[i] - mx);
+    row[i] = e;
+    sum += e;
+  }
+  sum = fh::block_sum_256(sum, redd);
+  const float inv = (float)(1.0 / sum);
+  for (int i = threadIdx.x; i < T; i += 256) row[i] *= inv;
+}
+
+__global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restrict__ p, float* __restrict__ dp, int T) {
+  __shared__ double redd[4];
+  const float* pr = p + (int64_t)blockIdx.x * T;
+  float* dr = dp + (int64_t)blockIdx.x * T;
+  double dot = 0.0;
+  for (int i = threadIdx.x; i < T; i += 256) dot += (double)pr[i] * dr[i];
+  dot = fh::block_sum_256(dot, redd);
+  const float d = (float)dot;
+  for (int i = threadIdx.x; i < T; i += 256) dr[i] = pr[i] * (dr[i] - d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resampling, concat and layout changes (NHWC, float4 along C)
+// ------------------------------------------------------------------------------------------------
+// mode 0: 2x2 average pool  [N][H][W][C] -> [N][H/2][W/2][C]        mode 1: its adjoint (grad / 4 to 4 pixels)
+// mode 2: nearest 2x upsample [N][H][W][C] -> [N][2H][2W][C]        mode 3: its adjoint (sum of 4 grads)
+__global__ __launch_bounds__(256) void k_resample(const float* __restrict__ in, float* __restrict__ out, int N, int H,
+                                                  int W, int C, int mode) {
+  // H, W are always the SMALL side's dimensions
+  const bool to_small = (mode == 0 || mode == 3);
+  const int C4 = C / 4;
+  const int64_t total = to_small ? (int64_t)N * H * W * C4 : (int64_t)N * 4 * H * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    if (to_small) {
+      const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+      const float4* src = reinterpret_cast<const float4*>(in) + (((int64_t)n * 2 * H + 2 * h) * 2 * W + 2 * w) * C4 + c4;
+      const float4 a = src[0], b = src[C4], c = src[(int64_t)2 * W * C4], d = src[(int64_t)2 * W * C4 + C4];
+      const float f = mode == 0 ? 0.25f : 1.f;
+      reinterpret_cast<float4*>(out)[i] = make_float4(f * (a.x + b.x + c.x + d.x), f * (a.y + b.y + c.y + d.y),
+                                                      f * (a.z + b.z + c.z + d.z), f * (a.w + b.w + c.w + d.w));
+    } else {
+      const int w = (int)(p % (2 * W)), h = (int)((p / (2 * W)) % (2 * H)), n = (int)(p / ((int64_t)4 * W * H));
+      float4 v = reinterpret_cast<const float4*>(in)[(((int64_t)n * H + h / 2) * W + w / 2) * C4 + c4];
+      if (mode == 1) v = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+      reinterpret_cast<float4*>(out)[i] = v;
+    }
+  }
+}
+
+// out[p][0:Ca] = a[p], out[p][Ca:Ca+Cb] = b[p]   (split = 1: the reverse, out -> a, b)
+__global__ __launch_bounds__(256) void k_concat(float* __restrict__ a, float* __restrict__ b, float* __restrict__ out,
+                                                int64_t P, int Ca, int Cb, int split) {
+  const int C4 = (Ca + Cb) / 4, Ca4 = Ca / 4, Cb4 = Cb / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P * C4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t p = i / C4;
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    float4* s = c4 < Ca4 ? reinterpret_cast<float4*>(a) + p * Ca4 + c4 : reinterpret_cast<float4*>(b) + p * Cb4 + (c4 - Ca4);
+    if (split) *s = *o; else *o = *s;
+  }
+}
+
+// NCHW [N][C][P] <-> NHWC [N][P][Cp] (Cp >= C, extra channels zero / ignored)
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                      int C, int64_t P, int Cp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * P * Cp; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const int64_t p = (i / Cp) % P, n = i / (Cp * P);
+    out[i] = c < C ? in[((int64_t)n * C + c) * P + p] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                      int C, int64_t P, int Cp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)N * C * P; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i % P;
+    const int c = (int)((i / P) % C);
+    const int64_t n = i / (P * C);
+    out[i] = in[((int64_t)n * P + p) * Cp + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_add_f32(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+inline unsigned grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int N, int H,
+                   int W, int Cin, int Cout, int KH, int KW, int pad, int stride, void* stream) {
+  if (!in || !w || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
+    return FH_EINVAL;
+  ConvArgs a;
+  a.in = in, a.w = w, a.bias = bias, a.res = res, a.out = out;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
+  a.Ho = (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  const int64_t M = (int64_t)N * a.Ho * a.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice: 128x128 when it still yields >= 2 workgroups per CU, else shrink M, then N
+  const int64_t b128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+  if (Cout > 64 && b128 >= 384) {
+    hipLaunchKernelGGL((k_conv_igemm<2, 2>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128), dim3(256), 0, st, a);
+  } else if (Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
+    hipLaunchKernelGGL((k_conv_igemm<1, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_conv_igemm<1, 1>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64), dim3(256), 0, st, a);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                 int transB, int batch, int inner, int64_t sA0, int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0,
+                 int64_t sC1, float alpha, void* stream) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || inner < 1) return FH_EINVAL;
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.inner = inner;
+  g.sA0 = sA0, g.sA1 = sA1, g.sB0 = sB0, g.sB1 = sB1, g.sC0 = sC0, g.sC1 = sC1, g.alpha = alpha;
+  dim3 grid((M + 63) / 64, (N + 63) / 64, batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (!transA && !transB) hipLaunchKernelGGL((k_bgemm<0, 0>), grid, dim3(256), 0, st, g);
+  else if (!transA && transB) hipLaunchKernelGGL((k_bgemm<0, 1>), grid, dim3(256), 0, st, g);
+  else if (transA && !transB) hipLaunchKernelGGL((k_bgemm<1, 0>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((k_bgemm<1, 1>), grid, dim3(256), 0, st, g);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_groupnorm_stats(const float* x, float* stats, int N, int P, int C, void* stream) {
+  if (!x || !stats || C % 32 != 0) return FH_EINVAL;
+  hipLaunchKernelGGL(k_gn_stats, dim3(N * 32), dim3(256), 0, (hipStream_t)stream, x, stats, P, C);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* scale,
+                       const float* shift, int ss_stride, float* y, int N, int P, int C, int act, void* stream) {
+  if (!x || !stats || !gamma || !beta || !y || C % 32 != 0) return FH_EINVAL;
+  const int64_t total = (int64_t)N * P * C;
+  hipLaunchKernelGGL(k_gn_apply, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta,
+                     scale, shift, ss_stride, y, total, P, C, act);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                     const float* scale, const float* shift, int ss_stride, float* sums, float* dx, int N, int P, int C,
+                     int act, int accumulate, void* stream) {
+  if (!x || !dy || !stats || !gamma || !beta || !sums || !dx || C % 32 != 0) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)N * P * C;
+  hipLaunchKernelGGL(k_gn_bwd_stats, dim3(N * 32), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
+                     ss_stride, sums, P, C, act);
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(grid_for(total, 1024)), dim3(256), 0, st, x, dy, stats, (const float*)sums,
+                     gamma, beta, scale, shift, ss_stride, dx, total, P, C, act, accumulate);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_softmax_rows(float* s, int64_t rows, int T, void* stream) {
+  if (!s || rows < 1 || T < 1) return FH_EINVAL;
+  hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, T);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int T, void* stream) {
+  if (!p || !dp || rows < 1 || T < 1) return FH_EINVAL;
+  hipLaunchKernelGGL(k_softmax_bwd_rows, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, T);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_resample2x(const float* in, float* out, int N, int Hs, int Ws, int C, int mode, void* stream) {
+  if (!in || !out || C % 4 != 0 || mode < 0 || mode > 3) return FH_EINVAL;
+  const int64_t items = (int64_t)N * Hs * Ws * (C / 4) * ((mode == 0 || mode == 3) ? 1 : 4);
+  hipLaunchKernelGGL(k_resample, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, in, out, N, Hs, Ws, C, mode);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_concat_channels(float* a, float* b, float* out, int64_t P, int Ca, int Cb, int split, void* stream) {
+  if (!a || !b || !out || Ca % 4 != 0 || Cb % 4 != 0) return FH_EINVAL;
+  hipLaunchKernelGGL(k_concat, dim3(grid_for(P * ((Ca + Cb) / 4))), dim3(256), 0, (hipStream_t)stream, a, b, out, P, Ca,
+                     Cb, split);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_layout_nchw_nhwc(const float* in, float* out, int N, int C, int64_t P, int Cp, int to_nhwc, void* stream) {
+  if (!in || !out || Cp < C) return FH_EINVAL;
+  if (to_nhwc)
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(grid_for((int64_t)N * P * Cp)), dim3(256), 0, (hipStream_t)stream, in, out, N,
+                       C, P, Cp);
+  else
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(grid_for((int64_t)N * P * C)), dim3(256), 0, (hipStream_t)stream, in, out, N,
+                       C, P, Cp);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n % 4 != 0) return FH_EINVAL;
+  hipLaunchKernelGGL(k_add_f32, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

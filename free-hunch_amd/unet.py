@@ -255,6 +255,7 @@ class UNetModel(torch.nn.Module):
         self.img_channels, self.img_resolution, self.label_dim = cfg.in_channels, cfg.image_size, 0
         self.sigma_min, self.sigma_max = 0.0, 1e20
         self._ops = None
+        self._emb = {}
 
     # the reference's key names in and out ------------------------------------------------------------
     def state_dict(self, *a, **k):
@@ -272,6 +273,7 @@ class UNetModel(torch.nn.Module):
                 if k in sd:
                     getattr(self, safe).copy_(sd[k])
         self._ops = None
+        self._emb = {}
         return self
 
     def _params(self):
@@ -290,15 +292,25 @@ class UNetModel(torch.nn.Module):
 
     def _apply(self, fn, *a, **k):  # moving / casting the module invalidates prepared weights
         self._ops = None
+        self._emb = {}
         return super()._apply(fn, *a, **k)
 
     def forward(self, x, timesteps, y=None, class_labels=None):
         assert y is None and class_labels is None, "unconditional checkpoints only"
         P = self._params()
-        emb = timestep_embedding(timesteps, self.cfg.num_channels)
-        emb = F.linear(emb, P["time_embed.0.weight"], P["time_embed.0.bias"])
-        emb = F.linear(F.silu(emb), P["time_embed.2.weight"], P["time_embed.2.bias"])
-        return self._backend_ops().run(self.steps, x.float(), emb)
+        ops = self._backend_ops()
+        key = tuple(timesteps.tolist())  # the embedding MLPs depend on the timestep only: cached per sigma
+        emb = self._emb.get(key)
+        if emb is None:
+            emb = timestep_embedding(timesteps, self.cfg.num_channels)
+            emb = F.linear(emb, P["time_embed.0.weight"], P["time_embed.0.bias"])
+            emb = F.linear(F.silu(emb), P["time_embed.2.weight"], P["time_embed.2.bias"])
+            if len(self._emb) > 4096:
+                self._emb.clear()
+            self._emb[key] = emb
+        if hasattr(ops, "emb_key"):
+            ops.emb_key = key
+        return ops.run(self.steps, x.float(), emb)
 
 
 def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,

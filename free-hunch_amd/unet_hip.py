@@ -1,7 +1,319 @@
-"""HIP execution of the UNet step list.  Bring-up state: delegates to the PyTorch-ROCm ops while the gfx950
-conv / GroupNorm / attention kernels land one by one ("UNet kernels")."""
-from .unet import _TorchOps
+"""Execution of the UNet step list on the gfx950 kernels of libfh_hip.so (forward and input-VJP).
+
+Activations are NHWC float32 tensors in HBM (torch only owns the memory).  The whole network is ONE
+`torch.autograd.Function`: the forward pass records what the input-gradient needs (GroupNorm inputs and
+statistics, attention probabilities, qkv) on a tape, the backward pass walks the tape in reverse with the
+dgrad / GroupNorm-backward / attention-backward kernels.  Weight gradients are never formed - the Free Hunch
+path only needs J^T v with respect to the image (conditioning_mechanisms.py:280).
+
+Weights are repacked once per device: conv weights [Cout][Cin][kh][kw] -> [Cout][taps][Cin] for the forward
+implicit GEMM and -> [Cin][taps flipped][Cout] for the input gradient (Cin / Cout zero-padded to a multiple
+of 32 where they are the GEMM K dimension).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_K = 32  # K granularity of fh_conv2d_nhwc
 
 
-class HipOps(_TorchOps):
-    pass
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+class _Conv:
+    def __init__(self, w, b):
+        co, ci = w.shape[0], w.shape[1]
+        kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)  # conv1d qkv / proj_out are 1x1
+        w4 = w.reshape(co, ci, kh, kw).float()
+        self.co, self.ci, self.kh, self.kw = co, ci, kh, kw
+        self.ci_p, self.co_p = _pad_to(ci, _K), _pad_to(co, _K)
+        wf = torch.zeros(co, kh * kw, self.ci_p, dtype=torch.float32, device=w.device)
+        wf[:, :, :ci] = w4.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+        wd = torch.zeros(ci, kh * kw, self.co_p, dtype=torch.float32, device=w.device)
+        wd[:, :, :co] = w4.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, kh * kw, co)
+        self.wf, self.wd, self.b = wf.contiguous(), wd.contiguous(), b.float().contiguous()
+
+
+class HipOps:
+    def __init__(self, cfg, P):
+        self.cfg = cfg
+        self.lib = _lib.load()
+        self.P = P
+        self.conv = {}
+        for k, v in P.items():
+            if k.endswith(".weight") and v.dim() >= 3:
+                name = k[: -len(".weight")]
+                self.conv[name] = _Conv(v.detach(), P[name + ".bias"].detach())
+        self._emb_cache = {}
+        self.emb_key = None  # set by UNetModel.forward: the timestep tuple the embeddings depend on
+
+    # ---------------------------------------------------------------- kernel wrappers
+    def _conv(self, name, x, res=None, bias_override=None):
+        c = self.conv[name]
+        N, H, W, Ci = x.shape
+        assert Ci == c.ci_p, (name, x.shape, c.ci_p)
+        pad = c.kh // 2
+        out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
+        b = c.b if bias_override is None else bias_override
+        _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
+                                           None if res is None else res.data_ptr(), out.data_ptr(), N, H, W, Ci, c.co,
+                                           c.kh, c.kw, pad, 1, _lib.stream()), "fh_conv2d_nhwc")
+        return out
+
+    def _dgrad(self, name, g, res=None):
+        c = self.conv[name]
+        N, H, W, Co = g.shape
+        if Co != c.co_p:  # only the 6-channel output conv: pad the cotangent to the K granularity
+            gp = torch.zeros(N, H, W, c.co_p, dtype=torch.float32, device=g.device)
+            gp[..., :Co] = g
+            g = gp
+        out = torch.empty(N, H, W, c.ci, dtype=torch.float32, device=g.device)
+        _lib.check(self.lib.fh_conv2d_nhwc(g.data_ptr(), c.wd.data_ptr(), None,
+                                           None if res is None else res.data_ptr(), out.data_ptr(), N, H, W, c.co_p,
+                                           c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_nhwc(dgrad)")
+        return out
+
+    def _gn(self, name, x, act, scale=None, shift=None):
+        N, H, W, C = x.shape
+        stats = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        st = _lib.stream()
+        _lib.check(self.lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), N, H * W, C, st), "gn_stats")
+        ss = 0 if scale is None else scale.stride(0)
+        _lib.check(self.lib.fh_groupnorm_apply(
+            x.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(), self.P[name + ".bias"].data_ptr(),
+            None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss,
+            y.data_ptr(), N, H * W, C, int(act), st), "gn_apply")
+        return y, stats
+
+    def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None):
+        N, H, W, C = x.shape
+        sums = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
+        dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
+        ss = 0 if scale is None else scale.stride(0)
+        _lib.check(self.lib.fh_groupnorm_bwd(
+            x.data_ptr(), dy.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(),
+            self.P[name + ".bias"].data_ptr(), None if scale is None else scale.data_ptr(),
+            None if shift is None else shift.data_ptr(), ss, sums.data_ptr(), dx.data_ptr(), N, H * W, C, int(act),
+            int(accumulate_into is not None), _lib.stream()), "gn_bwd")
+        return dx
+
+    def _resample(self, x, mode):
+        N, H, W, C = x.shape
+        hs, ws = (H // 2, W // 2) if mode in (0, 3) else (H, W)
+        oh, ow = (hs, ws) if mode in (0, 3) else (2 * H, 2 * W)
+        out = torch.empty(N, oh, ow, C, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.fh_resample2x(x.data_ptr(), out.data_ptr(), N, hs, ws, C, mode, _lib.stream()), "resample")
+        return out
+
+    def _add(self, a, b):
+        out = torch.empty_like(a)
+        _lib.check(self.lib.fh_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.stream()), "add")
+        return out
+
+    def _bgemm(self, A, B, Cm, M, N, K, lda, ldb, ldc, ta, tb, batch, inner, sA, sB, sC, alpha=1.0):
+        _lib.check(self.lib.fh_bgemm_f32(A, B, Cm, M, N, K, lda, ldb, ldc, ta, tb, batch, inner, sA[0], sA[1], sB[0],
+                                         sB[1], sC[0], sC[1], float(alpha), _lib.stream()), "fh_bgemm_f32")
+
+    # ---------------------------------------------------------------- timestep-embedding MLPs (depend on sigma only)
+    def emb_out(self, prefix, emb):
+        key = (self.emb_key, prefix)
+        e = self._emb_cache.get(key) if self.emb_key is not None else None
+        if e is None:
+            e = F.linear(F.silu(emb), self.P[prefix + ".emb_layers.1.weight"], self.P[prefix + ".emb_layers.1.bias"])
+            e = e.float().contiguous()
+            if self.emb_key is not None:
+                if len(self._emb_cache) > 4096:
+                    self._emb_cache.clear()
+                self._emb_cache[key] = e
+        return e
+
+    # ---------------------------------------------------------------- blocks
+    def _res_fwd(self, op, p, x, emb, tape):
+        cfg = self.cfg
+        h0, st0 = self._gn(p + ".in_layers.0", x, act=1)
+        xs = x
+        if op == "res_down":
+            h0, xs = self._resample(h0, 0), self._resample(x, 0)
+        elif op == "res_up":
+            h0, xs = self._resample(h0, 2), self._resample(x, 2)
+        e = self.emb_out(p, emb)  # [N, Co] or [N, 2 Co]
+        co = self.conv[p + ".in_layers.2"].co
+        if cfg.use_scale_shift_norm:
+            h1 = self._conv(p + ".in_layers.2", h0)
+            scale, shift = e[:, :co], e[:, co:]
+            h2, st1 = self._gn(p + ".out_layers.0", h1, act=1, scale=scale, shift=shift)
+        else:
+            if e.shape[0] != 1 and not bool((e == e[:1]).all()):
+                raise NotImplementedError("per-sample timestep embeddings without scale-shift norm")
+            h1 = self._conv(p + ".in_layers.2", h0, bias_override=(self.conv[p + ".in_layers.2"].b + e[0]).contiguous())
+            scale = shift = None
+            h2, st1 = self._gn(p + ".out_layers.0", h1, act=1)
+        skip = self._conv(p + ".skip_connection", xs) if (p + ".skip_connection") in self.conv else xs
+        out = self._conv(p + ".out_layers.3", h2, res=skip)
+        tape.append(("res", op, p, x, st0, h1, st1, scale, shift))
+        return out
+
+    def _res_bwd(self, rec, g):
+        _, op, p, x, st0, h1, st1, scale, shift = rec
+        g_h2 = self._dgrad(p + ".out_layers.3", g)
+        g_h1 = self._gn_bwd(p + ".out_layers.0", h1, st1, g_h2, 1, scale, shift)
+        g_h0 = self._dgrad(p + ".in_layers.2", g_h1)
+        g_xs = self._dgrad(p + ".skip_connection", g) if (p + ".skip_connection") in self.conv else g
+        if op == "res_down":
+            g_h0, g_xs = self._resample(g_h0, 1), self._resample(g_xs, 1)
+        elif op == "res_up":
+            g_h0, g_xs = self._resample(g_h0, 3), self._resample(g_xs, 3)
+        # (identity skip, no resampling: g_xs aliases g; every read of g is already enqueued on this stream)
+        return self._gn_bwd(p + ".in_layers.0", x, st0, g_h0, 1, accumulate_into=g_xs)
+
+    def _attn_geometry(self, N, T, C, heads):
+        ch = C // heads
+        if self.cfg.use_new_attention_order:
+            hs, qo, ko, vo = ch, 0, C, 2 * C
+        else:
+            hs, qo, ko, vo = 3 * ch, 0, ch, 2 * ch
+        return ch, hs, qo, ko, vo
+
+    def _attn_fwd(self, p, x, heads, tape):
+        N, H, W, C = x.shape
+        T = H * W
+        hn, st = self._gn(p + ".norm", x, act=0)
+        qkv = self._conv(p + ".qkv", hn)  # [N,H,W,3C]
+        ch, hs, qo, ko, vo = self._attn_geometry(N, T, C, heads)
+        S = torch.empty(N * heads, T, T, dtype=torch.float32, device=x.device)
+        base, fs = qkv.data_ptr(), 4
+        s3 = (T * 3 * C, hs)
+        self._bgemm(base + qo * fs, base + ko * fs, S.data_ptr(), T, T, ch, 3 * C, 3 * C, T, 0, 0, N * heads, heads,
+                    s3, s3, (heads * T * T, T * T), alpha=1.0 / math.sqrt(ch))
+        _lib.check(self.lib.fh_softmax_rows(S.data_ptr(), N * heads * T, T, _lib.stream()), "softmax")
+        A = torch.empty(N, H, W, C, dtype=torch.float32, device=x.device)
+        self._bgemm(S.data_ptr(), base + vo * fs, A.data_ptr(), T, ch, T, T, 3 * C, C, 0, 1, N * heads, heads,
+                    (heads * T * T, T * T), s3, (T * C, ch))
+        out = self._conv(p + ".proj_out", A, res=x)
+        tape.append(("attn", p, x, st, qkv, S, heads))
+        return out
+
+    def _attn_bwd(self, rec, g):
+        _, p, x, st, qkv, S, heads = rec
+        N, H, W, C = x.shape
+        T = H * W
+        ch, hs, qo, ko, vo = self._attn_geometry(N, T, C, heads)
+        gA = self._dgrad(p + ".proj_out", g)  # [N,H,W,C]
+        dqkv = torch.empty_like(qkv)
+        base, dbase, fs = qkv.data_ptr(), dqkv.data_ptr(), 4
+        s3, sS, sA = (T * 3 * C, hs), (heads * T * T, T * T), (T * C, ch)
+        B_ = N * heads
+        # dV[s][c] = sum_t P[t][s] gA[t][c]
+        self._bgemm(S.data_ptr(), gA.data_ptr(), dbase + vo * fs, T, ch, T, T, C, 3 * C, 1, 1, B_, heads, sS, sA, s3)
+        # dP[t][s] = sum_c gA[t][c] V[s][c]
+        dP = torch.empty_like(S)
+        self._bgemm(gA.data_ptr(), base + vo * fs, dP.data_ptr(), T, T, ch, C, 3 * C, T, 0, 0, B_, heads, sA, s3, sS)
+        _lib.check(self.lib.fh_softmax_bwd_rows(S.data_ptr(), dP.data_ptr(), B_ * T, T, _lib.stream()), "softmax_bwd")
+        alpha = 1.0 / math.sqrt(ch)
+        # dQ[t][c] = alpha sum_s dS[t][s] K[s][c] ;  dK[s][c] = alpha sum_t dS[t][s] Q[t][c]
+        self._bgemm(dP.data_ptr(), base + ko * fs, dbase + qo * fs, T, ch, T, T, 3 * C, 3 * C, 0, 1, B_, heads, sS, s3, s3,
+                    alpha)
+        self._bgemm(dP.data_ptr(), base + qo * fs, dbase + ko * fs, T, ch, T, T, 3 * C, 3 * C, 1, 1, B_, heads, sS, s3, s3,
+                    alpha)
+        g_hn = self._dgrad(p + ".qkv", dqkv)
+        return self._gn_bwd(p + ".norm", x, st, g_hn, 0, accumulate_into=g)
+
+    # ---------------------------------------------------------------- whole network
+    def forward_tape(self, steps, x_nchw, emb):
+        cfg = self.cfg
+        N, Cin, H, W = x_nchw.shape
+        st = _lib.stream()
+        x = torch.empty(N, H, W, _pad_to(Cin, _K), dtype=torch.float32, device=x_nchw.device)
+        _lib.check(self.lib.fh_layout_nchw_nhwc(x_nchw.contiguous().data_ptr(), x.data_ptr(), N, Cin, H * W, x.shape[-1],
+                                                1, st), "layout")
+        tape, stack, h = [], [], x
+        for op, p, _ci, _co, heads in steps:
+            if op == "push":
+                stack.append(h)
+                tape.append(("push",))
+            elif op == "pop_cat":
+                s = stack.pop()
+                Nn, Hh, Ww, Ca = h.shape
+                Cb = s.shape[-1]
+                out = torch.empty(Nn, Hh, Ww, Ca + Cb, dtype=torch.float32, device=h.device)
+                _lib.check(self.lib.fh_concat_channels(h.data_ptr(), s.data_ptr(), out.data_ptr(), Nn * Hh * Ww, Ca, Cb,
+                                                       0, st), "concat")
+                tape.append(("pop_cat", Ca, Cb))
+                h = out
+            elif op == "conv_in":
+                h = self._conv(p, h)
+                tape.append(("conv", p))
+            elif op in ("res", "res_down", "res_up"):
+                h = self._res_fwd(op, p, h, emb, tape)
+            elif op == "attn":
+                h = self._attn_fwd(p, h, heads, tape)
+            else:
+                raise NotImplementedError(f"UNet step '{op}' (conv_resample up/down-sampling) has no HIP kernel yet; "
+                                          "the public 256x256 checkpoints use resblock_updown")
+        hn, stn = self._gn("out.0", h, act=1)
+        tape.append(("out", h, stn))
+        y = self._conv("out.2", hn)  # [N,H,W,out_channels]
+        co = y.shape[-1]
+        out = torch.empty(N, co, H, W, dtype=torch.float32, device=y.device)
+        _lib.check(self.lib.fh_layout_nchw_nhwc(y.data_ptr(), out.data_ptr(), N, co, H * W, co, 0, st), "layout")
+        return out, tape
+
+    def backward_tape(self, tape, g_nchw):
+        N, Co, H, W = g_nchw.shape
+        st = _lib.stream()
+        cp = self.conv["out.2"].co_p
+        g = torch.empty(N, H, W, cp, dtype=torch.float32, device=g_nchw.device)
+        _lib.check(self.lib.fh_layout_nchw_nhwc(g_nchw.contiguous().data_ptr(), g.data_ptr(), N, Co, H * W, cp, 1, st),
+                   "layout")
+        pending = []  # gradients of skip tensors, to be added when their `push` is reached
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "out":
+                _, h, stn = rec
+                g = self._dgrad("out.2", g)
+                g = self._gn_bwd("out.0", h, stn, g, 1)
+            elif kind == "res":
+                g = self._res_bwd(rec, g)
+            elif kind == "attn":
+                g = self._attn_bwd(rec, g)
+            elif kind == "pop_cat":
+                _, Ca, Cb = rec
+                Nn, Hh, Ww, _ = g.shape
+                ga = torch.empty(Nn, Hh, Ww, Ca, dtype=torch.float32, device=g.device)
+                gb = torch.empty(Nn, Hh, Ww, Cb, dtype=torch.float32, device=g.device)
+                _lib.check(self.lib.fh_concat_channels(ga.data_ptr(), gb.data_ptr(), g.data_ptr(), Nn * Hh * Ww, Ca, Cb,
+                                                       1, st), "split")
+                pending.append(gb)
+                g = ga
+            elif kind == "push":
+                g = self._add(g, pending.pop())
+            elif kind == "conv":
+                g = self._dgrad(rec[1], g)  # [N,H,W,3]
+        ci = g.shape[-1]
+        out = torch.empty(N, ci, H, W, dtype=torch.float32, device=g.device)
+        _lib.check(self.lib.fh_layout_nchw_nhwc(g.data_ptr(), out.data_ptr(), N, ci, H * W, ci, 0, st), "layout")
+        return out
+
+    def run(self, steps, x, emb):
+        return _UNetFn.apply(x, self, steps, emb)
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ops, steps, emb):
+        out, tape = ops.forward_tape(steps, x.detach(), emb.detach())
+        ctx.ops, ctx.tape = ops, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = ctx.ops.backward_tape(ctx.tape, g)
+        ctx.tape = None
+        return gx, None, None, None

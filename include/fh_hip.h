@@ -124,6 +124,57 @@ int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, v
 int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
                 int maxiter, fh_cg_info* info_host, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * UNet kernels (float32, activations NHWC [N][H][W][C] in HBM).  They replace the PyTorch modules of
+ * training/openai_unet.py / openai_nn.py that the denoiser call and its input-VJP run through
+ * (conditioning_mechanisms.py:239 forward, :280 autograd.grad):
+ *   conv3x3 / conv1x1 / their input gradients   openai_unet.py:98,131,185,211,222,286,294   -> fh_conv2d_nhwc
+ *   GroupNorm32 (+ scale/shift, + SiLU)          openai_nn.py:17-19, openai_unet.py:182-186,246-252 -> fh_groupnorm_*
+ *   QKV attention (both channel orders)          openai_unet.py:337-354, 370-384          -> fh_bgemm_f32 + fh_softmax_*
+ *   Upsample / AvgPool2d of resblock_updown      openai_unet.py:107,136                   -> fh_resample2x
+ *   torch.cat of the skip connections            openai_unet.py:683                       -> fh_concat_channels
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution on the fp32 matrix cores.  w is [Cout][KH*KW][Cin] (Cin innermost, Cin % 32 == 0);
+ * out = conv(in, w) + bias (+ res), out/res are [N][Ho][Wo][Cout].  The input gradient of a stride-1 convolution is
+ * the same call with the spatially flipped, in/out-transposed weight copy. */
+int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int N, int H,
+                   int W, int Cin, int Cout, int KH, int KW, int pad, int stride, void* stream);
+
+/* C[b] = alpha * opA(A[b]) * opB(B[b]), C [M][N] (ldc).  transA = 0: A is [M][K] (lda), 1: [K][M];
+ * transB = 0: B is [N][K] (ldb), 1: [K][N].  Batch b in [0, batch): offsets (b / inner) * s?0 + (b % inner) * s?1. */
+int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int transA,
+                 int transB, int batch, int inner, int64_t sA0, int64_t sA1, int64_t sB0, int64_t sB1, int64_t sC0,
+                 int64_t sC1, float alpha, void* stream);
+
+/* GroupNorm with 32 groups, eps = 1e-5, over x [N][P][C]:  stats [N][32][2] = (mean, rstd);
+ * y = act(((x - mean) * rstd * gamma + beta) * (1 + scale[n][c]) + shift[n][c]);  scale/shift may be null;
+ * scale[n] starts at scale + n * ss_stride;  act: 0 identity, 1 SiLU.
+ * bwd: dx (+)= d/dx of the above applied to dy; sums is [N][32][2] scratch. */
+int fh_groupnorm_stats(const float* x, float* stats, int N, int P, int C, void* stream);
+int fh_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* scale,
+                       const float* shift, int ss_stride, float* y, int N, int P, int C, int act, void* stream);
+int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                     const float* scale, const float* shift, int ss_stride, float* sums, float* dx, int N, int P, int C,
+                     int act, int accumulate, void* stream);
+
+/* in-place row softmax of s [rows][T];  backward in place on dp: dp <- p .* (dp - rowsum(dp .* p)) */
+int fh_softmax_rows(float* s, int64_t rows, int T, void* stream);
+int fh_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int T, void* stream);
+
+/* (Hs, Ws) = the SMALL side.  mode 0: 2x2 average pool big -> small; 1: its adjoint small -> big;
+ * 2: nearest 2x upsample small -> big; 3: its adjoint big -> small. */
+int fh_resample2x(const float* in, float* out, int N, int Hs, int Ws, int C, int mode, void* stream);
+
+/* split = 0: out[p] = [a[p] | b[p]] over P pixels;  split = 1: a, b <- the two channel ranges of out */
+int fh_concat_channels(float* a, float* b, float* out, int64_t P, int Ca, int Cb, int split, void* stream);
+
+/* to_nhwc = 1: in [N][C][P] -> out [N][P][Cp] (channels C..Cp-1 zero);  0: in [N][P][Cp] -> out [N][C][P] */
+int fh_layout_nchw_nhwc(const float* in, float* out, int N, int C, int64_t P, int Cp, int to_nhwc, void* stream);
+
+/* out = a + b over n floats (n % 4 == 0) */
+int fh_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,158 @@
+"""GPU parity of the hand-written UNet kernels: per-op against plain PyTorch fp32 references, whole network
+(forward + input-VJP) against the PyTorch-ROCm backend and against golden vectors from the reference."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cudnn.allow_tf32 = False
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def _lib():
+    from free_hunch_amd import _lib as L
+    return L, L.load()
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 128, 128, 3), (1, 16, 16, 256, 96, 3), (2, 8, 8, 64, 256, 3),
+                                   (1, 32, 32, 160, 64, 1), (1, 256, 256, 32, 128, 3), (1, 9, 13, 32, 6, 3)])
+def test_conv_forward_vs_torch(dev, shape):
+    L, lib = _lib()
+    N, H, W, Ci, Co, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    res = torch.randn(N, Co, H, W, generator=g).to(dev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=k // 2) + res.double()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wn = w.permute(0, 2, 3, 1).reshape(Co, k * k, Ci).contiguous()
+    rn = res.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(N, H, W, Co, device=dev)
+    L.check(lib.fh_conv2d_nhwc(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), N, H, W, Ci, Co,
+                               k, k, k // 2, 1, L.stream()), "conv")
+    # exact-fp32 MFMA accumulation: error ~ 1e-7 * sum|a b|
+    assert rel(out.permute(0, 3, 1, 2), ref) < 5e-6
+
+
+def test_bgemm_all_transposes(dev):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    M, N, K, batch = 100, 70, 50, 3
+    A = torch.randn(batch, M, K, generator=g).to(dev)
+    B = torch.randn(batch, N, K, generator=g).to(dev)
+    ref = 0.5 * torch.bmm(A.double(), B.double().transpose(1, 2))
+    for ta in (0, 1):
+        for tb in (0, 1):
+            Am = (A.transpose(1, 2) if ta else A).contiguous()
+            Bm = (B.transpose(1, 2) if tb else B).contiguous()
+            C = torch.empty(batch, M, N, device=dev)
+            L.check(lib.fh_bgemm_f32(Am.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K, Am.shape[2], Bm.shape[2], N, ta,
+                                     tb, batch, 1, M * K, 0, N * K, 0, M * N, 0, 0.5, L.stream()), "bgemm")
+            assert rel(C, ref) < 5e-6, (ta, tb)
+
+
+@pytest.mark.parametrize("act,ss", [(1, True), (1, False), (0, False)])
+def test_groupnorm_fwd_bwd_vs_torch(dev, act, ss):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    N, H, W, C = 2, 12, 10, 96
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dev).requires_grad_()
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    e = torch.randn(N, 2 * C, generator=g).to(dev)
+    dy = torch.randn(N, C, H, W, generator=g).to(dev)
+    t = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if ss:
+        t = t * (1 + e[:, :C, None, None]) + e[:, C:, None, None]
+    ref = F.silu(t) if act else t
+    (gref,) = torch.autograd.grad((ref * dy).sum(), x)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous()
+    dyn = dy.permute(0, 2, 3, 1).contiguous()
+    stats, sums = torch.empty(N, 32, 2, device=dev), torch.empty(N, 32, 2, device=dev)
+    y, dx = torch.empty_like(xn), torch.empty_like(xn)
+    sc, sh = (e[:, :C], e[:, C:]) if ss else (None, None)
+    st = L.stream()
+    L.check(lib.fh_groupnorm_stats(xn.data_ptr(), stats.data_ptr(), N, H * W, C, st), "stats")
+    L.check(lib.fh_groupnorm_apply(xn.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                   sc.data_ptr() if ss else None, sh.data_ptr() if ss else None, 2 * C, y.data_ptr(), N,
+                                   H * W, C, act, st), "apply")
+    L.check(lib.fh_groupnorm_bwd(xn.data_ptr(), dyn.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                 sc.data_ptr() if ss else None, sh.data_ptr() if ss else None, 2 * C, sums.data_ptr(),
+                                 dx.data_ptr(), N, H * W, C, act, 0, st), "bwd")
+    assert rel(y.permute(0, 3, 1, 2), ref.detach()) < 2e-5
+    assert rel(dx.permute(0, 3, 1, 2), gref) < 5e-5
+
+
+def _pair(cfg_o, seed, dev):
+    from free_hunch_amd import unet as hu
+    kw = {k: getattr(cfg_o, k) for k in ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma",
+                                         "attention_resolutions", "num_heads", "num_head_channels",
+                                         "use_scale_shift_norm", "resblock_updown", "use_new_attention_order")}
+    cfg = hu.UNetConfig(**kw)
+    sd = hu.seeded_state(cfg, seed)
+    nets = []
+    for backend in ("hip", "torch"):
+        m = hu.UNetModel(cfg, backend=backend)
+        m.load_state_dict(sd)
+        nets.append(m.to(dev).eval())
+    return nets, cfg
+
+
+NEW_ORDER = inputs.SMALL_A.__class__(**{**inputs.SMALL_A.__dict__, "use_new_attention_order": True,
+                                        "use_scale_shift_norm": False})
+
+
+@pytest.mark.parametrize("which", ["A", "A_new_order_plain_norm"])
+def test_unet_hip_vs_torch_backend(dev, which):
+    cfg_o = inputs.SMALL_A if which == "A" else NEW_ORDER
+    (hip, ref), cfg = _pair(cfg_o, 11, dev)
+    x = (inputs.randn((2, 3, 64, 64), 3, torch.float32) * 0.7).to(dev)
+    t = torch.tensor([500, 500], device=dev)
+    cot = inputs.randn((2, cfg.out_channels, 64, 64), 4, torch.float32).to(dev)
+    outs = []
+    for m in (hip, ref):
+        xi = x.clone().requires_grad_()
+        y = m(xi, t)
+        (gx,) = torch.autograd.grad((y * cot).sum(), xi)
+        outs.append((y.detach(), gx))
+    assert rel(outs[0][0], outs[1][0]) < 2e-4
+    assert rel(outs[0][1], outs[1][1]) < 5e-4
+
+
+def test_unet_hip_vs_reference_golden(dev, gold):
+    """Raw UNet output, preconditioned denoiser and its input-VJP against vectors produced by the reference's own
+    UNetModel / iDDPMLinearPrecond (tests/golden/unet_a.npz)."""
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+    g = gold("unet_a")
+    seed = int(g["seed"])
+    (hip, _), cfg = _pair(inputs.SMALL_A, seed, dev)
+    net = iDDPMLinearPrecond(hip, 64, 3).to(dev)
+    x = (inputs.randn((1, 3, 64, 64), seed + 100) * 3.0).to(dev)
+    for j in range(3):
+        sigma = torch.tensor(float(g[f"sigma_{j}"]), dtype=torch.float64, device=dev)
+        with torch.no_grad():
+            c_in = 1 / (sigma ** 2 + 1).sqrt()
+            raw = hip(c_in.float() * x.float(), torch.from_numpy(g[f"tstep_{j}"]).long().flatten().to(dev))
+        ref = torch.from_numpy(g[f"raw_{j}"]).to(dev)
+        assert rel(raw, ref) < 5e-4
+        xt = x.clone().requires_grad_()
+        D, var = net(xt, sigma)
+        assert float((D - torch.from_numpy(g[f"D_{j}"]).to(dev)).abs().max()) < 1e-3
+        cot = inputs.randn(D.shape, seed + 200 + j).to(D.dtype).to(dev)
+        (vjp,) = torch.autograd.grad((cot * D).sum(), xt)
+        assert rel(vjp, torch.from_numpy(g[f"vjp_{j}"]).to(dev)) < 2e-3
