@@ -239,28 +239,98 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
 //   k_gn_apply : y = act( ((x - mean) * rstd * gamma + beta) * (1 + scale[n][c]) + shift[n][c] ),  act = SiLU or id
 //   k_gn_bwd_* : dx given dy (through act, scale/shift, affine and the normalisation)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ x, float* __restrict__ stats, int P,
-                                                  int C) {
-  __shared__ double red[4];
-  const int n = blockIdx.x / 32, grp = blockIdx.x % 32, cg = C / 32;
-  const float* base = x + (int64_t)n * P * C + grp * cg;
-  const int64_t total = (int64_t)P * cg;
-  double s = 0.0, ss = 0.0;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t p = i / cg;
-    const int c = (int)(i % cg);
-    const float v = base[p * C + c];
-    s += v;
-    ss += (double)v * v;
+constexpr int kGnChunk = 512;  // pixels per workgroup in the statistics passes
+
+// Shared skeleton of the two statistics passes.  Workgroup = (image n, chunk of kGnChunk pixels); a thread owns one
+// float4 of channels (fixed over its pixel loop), accumulates two double sums per channel, folds them into 32 group
+// slots in LDS, and the workgroup writes its 64 partial sums.  MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat)
+// with g = dL/d(xhat) rebuilt from dy through act / scale-shift / affine.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, int ss_stride,
+                                                    double* __restrict__ partial, int P, int C, int act, int nchunks) {
+  __shared__ double acc[64];
+  const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  const int cg = C / 32, c4n = C / 4;
+  if (threadIdx.x < 64) acc[threadIdx.x] = 0.0;
+  __syncthreads();
+  const int p0 = chunk * kGnChunk;
+  const int p1 = p0 + kGnChunk < P ? p0 + kGnChunk : P;
+  const int lanes_p = c4n >= 256 ? 1 : 256 / c4n;  // pixel lanes
+  const int active = c4n >= 256 ? 256 : lanes_p * c4n;
+  if ((int)threadIdx.x < active) {
+    for (int c4 = threadIdx.x % (c4n < 256 ? c4n : 256); c4 < c4n; c4 += 256) {
+      const int psub = c4n >= 256 ? 0 : threadIdx.x / c4n;
+      double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+      float ga[4], be[4], sc[4], sh[4], mean[4], rstd[4];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * c4 + e;
+          ga[e] = gamma[c], be[e] = beta[c];
+          sc[e] = scale != nullptr ? 1.f + scale[(int64_t)n * ss_stride + c] : 1.f;
+          sh[e] = shift != nullptr ? shift[(int64_t)n * ss_stride + c] : 0.f;
+          mean[e] = stats[((int64_t)n * 32 + c / cg) * 2], rstd[e] = stats[((int64_t)n * 32 + c / cg) * 2 + 1];
+        }
+      }
+      for (int p = p0 + psub; p < p1; p += lanes_p) {
+        const int64_t idx = ((int64_t)n * P + p) * C + 4 * c4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + idx);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += xs[e];
+            s1[e] += (double)xs[e] * xs[e];
+          }
+        } else {
+          const float4 gv = *reinterpret_cast<const float4*>(dy + idx);
+          const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - mean[e]) * rstd[e];
+            const float t = (xh * ga[e] + be[e]) * sc[e] + sh[e];
+            float g = gs[e];
+            if (act) {
+              const float sg = 1.f / (1.f + __expf(-t));
+              g *= sg * (1.f + t * (1.f - sg));
+            }
+            g *= sc[e] * ga[e];
+            s0[e] += g;
+            s1[e] += (double)g * xh;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int grp = (4 * c4 + e) / cg;
+        atomicAdd(&acc[2 * grp], s0[e]);
+        atomicAdd(&acc[2 * grp + 1], s1[e]);
+      }
+    }
   }
-  s = fh::block_sum_256(s, red);
-  ss = fh::block_sum_256(ss, red);
-  if (threadIdx.x == 0) {
-    const double mean = s / total;
-    double var = ss / total - mean * mean;
+  __syncthreads();
+  if (threadIdx.x < 64) partial[(int64_t)blockIdx.x * 64 + threadIdx.x] = acc[threadIdx.x];
+}
+
+// MODE 0 -> (mean, rstd);  MODE 1 -> (mean g, mean g*xhat)
+template <int MODE>
+__global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ partial, float* __restrict__ out,
+                                                    int nchunks, double count) {
+  const int n = blockIdx.x, grp = threadIdx.x >> 1, which = threadIdx.x & 1;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += partial[((int64_t)n * nchunks + c) * 64 + threadIdx.x];
+  const double other = __shfl_xor(s, 1, 64);
+  if (MODE == 1) {
+    out[((int64_t)n * 32 + grp) * 2 + which] = (float)(s / count);
+  } else {
+    const double sum = which ? other : s, sq = which ? s : other;
+    const double mean = sum / count;
+    double var = sq / count - mean * mean;
     var = var < 0 ? 0 : var;
-    stats[(int64_t)blockIdx.x * 2] = (float)mean;
-    stats[(int64_t)blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    out[((int64_t)n * 32 + grp) * 2 + which] = which ? (float)(1.0 / sqrt(var + 1e-5)) : (float)mean;
   }
 }
 
@@ -286,45 +356,6 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, c
       v[e] = act ? silu_f(t) : t;
     }
     *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-}
-
-// backward pass 1: per (n, group) sums  a = sum(g),  b = sum(g * xhat)   with g = dL/d(xhat) (after act/scale/affine)
-__global__ __launch_bounds__(256) void k_gn_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy,
-                                                      const float* __restrict__ stats,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      int ss_stride, float* __restrict__ sums, int P, int C, int act) {
-  __shared__ double red[4];
-  const int n = blockIdx.x / 32, grp = blockIdx.x % 32, cg = C / 32;
-  const int64_t off = (int64_t)n * P * C + grp * cg;
-  const float mean = stats[(int64_t)blockIdx.x * 2], rstd = stats[(int64_t)blockIdx.x * 2 + 1];
-  const int64_t total = (int64_t)P * cg;
-  double sa = 0.0, sb = 0.0;
-  for (int64_t i = threadIdx.x; i < total; i += 256) {
-    const int64_t p = i / cg;
-    const int c = grp * cg + (int)(i % cg);
-    const int64_t idx = off + p * C + (c - grp * cg);
-    const float xh = (x[idx] - mean) * rstd;
-    float gsc = 1.f, t = xh * gamma[c] + beta[c];
-    if (scale != nullptr) {
-      gsc = 1.f + scale[(int64_t)n * ss_stride + c];
-      t = t * gsc + shift[(int64_t)n * ss_stride + c];
-    }
-    float g = dy[idx];
-    if (act) {
-      const float sg = 1.f / (1.f + __expf(-t));
-      g *= sg * (1.f + t * (1.f - sg));
-    }
-    g *= gsc * gamma[c];
-    sa += g;
-    sb += (double)g * xh;
-  }
-  sa = fh::block_sum_256(sa, red);
-  sb = fh::block_sum_256(sb, red);
-  if (threadIdx.x == 0) {
-    sums[(int64_t)blockIdx.x * 2] = (float)(sa / total);
-    sums[(int64_t)blockIdx.x * 2 + 1] = (float)(sb / total);
   }
 }
 
@@ -530,9 +561,35 @@ int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
   return 0;
 }
 
+static double* gn_scratch(int N, int nchunks, hipStream_t st) {
+  // per-device scratch for the chunk partials (grown on demand, outside any timed region after warm-up)
+  static double* buf[16] = {nullptr};
+  static size_t cap[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t need = (size_t)N * nchunks * 64 * sizeof(double);
+  if (need > cap[dev & 15]) {
+    if (buf[dev & 15]) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(buf[dev & 15]);
+    }
+    if (hipMalloc(&buf[dev & 15], need * 2) != hipSuccess) return nullptr;
+    cap[dev & 15] = need * 2;
+  }
+  return buf[dev & 15];
+}
+
 int fh_groupnorm_stats(const float* x, float* stats, int N, int P, int C, void* stream) {
   if (!x || !stats || C % 32 != 0) return FH_EINVAL;
-  hipLaunchKernelGGL(k_gn_stats, dim3(N * 32), dim3(256), 0, (hipStream_t)stream, x, stats, P, C);
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  double* part = gn_scratch(N, nchunks, st);
+  if (!part) return (int)hipErrorOutOfMemory;
+  hipLaunchKernelGGL(k_gn_partial<0>, dim3(N * nchunks), dim3(256), 0, st, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, part, P, C, 0, nchunks);
+  hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(64), 0, st, (const double*)part, stats, nchunks,
+                     (double)P * (C / 32));
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -553,8 +610,13 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
   if (!x || !dy || !stats || !gamma || !beta || !sums || !dx || C % 32 != 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)N * P * C;
-  hipLaunchKernelGGL(k_gn_bwd_stats, dim3(N * 32), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
-                     ss_stride, sums, P, C, act);
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  double* part = gn_scratch(N, nchunks, st);
+  if (!part) return (int)hipErrorOutOfMemory;
+  hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
+                     ss_stride, part, P, C, act, nchunks);
+  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(64), 0, st, (const double*)part, sums, nchunks,
+                     (double)P * (C / 32));
   hipLaunchKernelGGL(k_gn_bwd_apply, dim3(grid_for(total, 1024)), dim3(256), 0, st, x, dy, stats, (const float*)sums,
                      gamma, beta, scale, shift, ss_stride, dx, total, P, C, act, accumulate);
   FH_LAUNCH_CHECK();

@@ -33,15 +33,18 @@ for name in ("gaussian_blur","motion_blur","inpainting","super_resolution"):
 
 # UNet (PyTorch-ROCm bring-up backend) forward + input-VJP at the two benchmark architectures
 from bench import build_net
+import sys
 for arch in ("ffhq", "imagenet"):
-    net, cfg = build_net(arch, dev, "torch")
-    x = torch.randn(1,3,256,256, device=dev, dtype=torch.float64)
-    sig = torch.tensor(5.0, dtype=torch.float64, device=dev)
-    for it in range(3):
+  for backend in ("hip",):
+    net, cfg = build_net(arch, dev, backend)
+    for bs in (1, 8):
+      x = torch.randn(bs,3,256,256, device=dev, dtype=torch.float64)
+      sig = torch.tensor(5.0, dtype=torch.float64, device=dev)
+      for it in range(3):
         torch.cuda.synchronize(); t0=time.time()
         xt = x.clone().requires_grad_()
         D,_ = net(xt, sig)
         torch.cuda.synchronize(); t1=time.time()
         g, = torch.autograd.grad((D*D.detach()).sum(), xt)
         torch.cuda.synchronize(); t2=time.time()
-    print(arch, "torch UNet fwd %.1f ms  vjp %.1f ms" % ((t1-t0)*1e3, (t2-t1)*1e3))
+      print(arch, backend, "batch", bs, "UNet fwd %.1f ms  vjp %.1f ms" % ((t1-t0)*1e3, (t2-t1)*1e3), flush=True)
