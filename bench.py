@@ -59,25 +59,27 @@ def build_net(arch, device, backend):
 
 
 def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir):
-    """B independent images through the sampler; returns uint8 [B,3,S,S] on the device."""
+    """B independent images in lock-step through the sampler; returns uint8 [B,3,S,S] on the device."""
     from free_hunch_amd.measurements import get_operator
-    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler
+    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
     enc = StandardRGBEncoder()
     S = images_u8.shape[-1]
-    outs = []
-    for img, seed in zip(images_u8, seeds):
-        np.random.seed(int(seed))
-        torch.manual_seed(int(seed))
+    ops, ys, noises = [], [], []
+    for b, (img, seed) in enumerate(zip(images_u8, seeds)):
+        np.random.seed(int(seed) % (1 << 31))
+        torch.manual_seed(int(seed) % (1 << 31))
         op = get_operator(name=operator_name, device=device, sigma_s=0.1, kernel_size=61, intensity=1.0,
                           scale_factor=4, in_shape=(1, 3, S, S),
                           mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
                                     "mask_prob_range": (0.6, 0.8), "image_size": S})
-        x0 = enc.encode(img[None].to(device))
-        noise = torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(int(seed)), dtype=torch.float32)
-        x, _, _ = conditional_sampler(net, noise.to(device), x0, None, num_steps=num_steps, sigma_min=0.002,
-                                      sigma_max=80, rho=7, solver=solver, operator=op, **fh_kwargs(data_dir, solver))
-        outs.append(enc.decode(x))
-    return torch.cat(outs, 0)
+        op.ctx_slot = b
+        ops.append(op)
+        ys.append(op.forward(enc.encode(img[None].to(device)), noiseless=False))
+        noises.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(int(seed) % (1 << 31)),
+                                  dtype=torch.float32))
+    x = conditional_sampler_batched(net, torch.cat(noises, 0).to(device), ys, ops, num_steps=num_steps,
+                                    sigma_min=0.002, sigma_max=80, rho=7, solver=solver, **fh_kwargs(data_dir, solver))
+    return enc.decode(x)
 
 
 def roofline_cov_apply(device, m=32, iters=200):

@@ -113,8 +113,10 @@ class Context:
         self.h = h
 
     @classmethod
-    def get(cls, S, planes, m_cap):
-        key = (torch.cuda.current_device(), S, planes, m_cap)
+    def get(cls, S, planes, m_cap, slot=0):
+        """One context per (device, geometry, slot).  A context owns scratch buffers, so concurrent users (one image
+        per HIP stream / host thread) take different slots."""
+        key = (torch.cuda.current_device(), S, planes, m_cap, slot)
         if key not in cls._cache:
             cls._cache[key] = cls(S, planes, m_cap)
         return cls._cache[key]

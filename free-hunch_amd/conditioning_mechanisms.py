@@ -152,7 +152,8 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         s0 = float(init_noise_variance)
         base, common = argv["image_base_covariance"], dict(max_vector_count=argv["max_vector_count"],
                                                            project_to_diagonal=self.project_to_diagonal,
-                                                           device=device)
+                                                           device=device,
+                                                           ctx_slot=getattr(forward_operator, "ctx_slot", 0))
         if base == "identity":
             self.covariance_model = CovarianceHessianBFGS(init_denoiser_variance, s0, data_dim, **common)
         elif base in ("dct_diagonal", "dct_diagonal_noinfo"):
@@ -186,12 +187,18 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self.covariance_model.update_space_step(denoiser_mean_at_x, denoiser_mean_at_xnext, sigma_t, x, xnext)
 
     def x0_mean_update(self, x_t, model, y, sigma):
-        cm = self.covariance_model
-        rec = {}
         x_t = x_t.requires_grad_()
         x_0_mean, _ = model(x_t, sigma)
+        mat = self.fh_solve(x_t.detach(), x_0_mean.detach(), y, sigma, model)
+        p_y_xt_grad = grad((mat.detach() * x_0_mean).sum(), x_t)[0]
+        return self.fh_finish(mat, p_y_xt_grad, x_t.detach(), x_0_mean.detach(), sigma)
+
+    # The call is split in two so that a batch of independent images can share ONE UNet forward and ONE UNet
+    # input-VJP (sampler.conditional_sampler_batched): fh_solve = covariance updates + CG solve for one image,
+    # fh_finish = the 0.2-std branch and the history append.
+    def fh_solve(self, x_det, m_det, y, sigma, model=None):
+        cm = self.covariance_model
         s = float(sigma)
-        x_det, m_det = x_t.detach(), x_0_mean.detach()
         if self.do_space_updates:
             pred = None
             if len(self.sigmas) != 0 and s != self.sigmas[-1]:
@@ -208,12 +215,14 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         elif len(self.sigmas) != 0 and s != self.sigmas[-1]:
             score_previous = (self.denoiser_means[-1] - self.xs[-1]) / self.sigmas[-1] ** 2
             cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous, only_covariance=True)
-
         info = []
         mat = choose_solver(self.forward_operator.name, self.forward_operator, y, m_det, covariance_model=cm,
                             method=self.solver_type, max_rtol=self.max_rtol, sigma_t=s, info_out=info)
-        rec.update(info[0])
-        p_y_xt_grad = grad((mat.detach() * x_0_mean).sum(), x_t)[0]
+        self._rec = dict(info[0])
+        return mat
+
+    def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma):
+        cm, rec, s = self.covariance_model, self._rec, float(sigma)
         sig2 = torch.as_tensor(sigma, dtype=F64, device=m_det.device).pow(2)
         if (p_y_xt_grad * sig2).std() > self.denoiser_mean_error_threshold:
             p_y_xt_grad = cm.denoiser_cov_vector_dot(mat.detach(), use_cuda=True) * self.cond_scaling / sig2
@@ -225,8 +234,6 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         rec["k"], rec["sigma"] = cm.k, s
         if os.environ.get("FH_TRACE_SUMS"):  # debugging aid: costs a device sync per call
             rec["out_sum"] = float(x_0_mean_new.double().sum())
-            rec["mean_sum"] = float(m_det.double().sum())
-            rec["mat_sum"] = float(mat.double().sum())
         self.trace.append(rec)
         self.sigmas.append(s)
         self.xs.append(x_det)

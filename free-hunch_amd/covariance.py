@@ -83,7 +83,7 @@ class CovarianceHessianBFGS:
 
     def __init__(self, init_denoiser_variance, init_noise_variance, data_dim, dtype=None, max_vector_count=None,
                  init_denoiser_cov_u=None, project_to_diagonal=False, use_precalculated_info=True, device=None,
-                 m_cap=64):
+                 m_cap=64, ctx_slot=0):
         assert init_denoiser_cov_u is None, "a non-empty initial factor is not supported"
         self.device = torch.device(device if device is not None else "cuda")
         S = int(round(math.sqrt(data_dim / 3)))
@@ -92,7 +92,7 @@ class CovarianceHessianBFGS:
         self.S, self.data_dim = S, data_dim
         self.max_vector_count = max_vector_count
         self.project_to_diagonal = project_to_diagonal
-        self.ctx = _lib.Context.get(S, 3, _lib_max_cols())
+        self.ctx = _lib.Context.get(S, 3, _lib_max_cols(), ctx_slot)
         self.m_cap = m_cap
         d = data_dim
         var = torch.as_tensor(init_denoiser_variance, dtype=F64).reshape(-1).to(self.device)
@@ -260,7 +260,7 @@ def _blockdiag(M, a, b):
 
 
 def _lib_max_cols():
-    return 256
+    return 128  # column capacity of a context (Gram scratch grows with its square); Euler-100 needs 56
 
 
 class CovarianceHessianBFGSDCT(CovarianceHessianBFGS):

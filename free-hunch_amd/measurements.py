@@ -59,9 +59,11 @@ class Taps:
 class LinearOperator:
     device = None
 
+    ctx_slot = 0  # scratch-context slot; the batched sampler gives every concurrent image its own
+
     def _ctx(self):
         S = self.in_shape[-1]
-        return _lib.Context.get(S, 3, 256)
+        return _lib.Context.get(S, 3, 128, self.ctx_slot)
 
     def _conv(self, x, stride=1, adjoint=False):
         """float64 circular convolution of an NCHW tensor (N = 1) with self.taps; returns float64."""

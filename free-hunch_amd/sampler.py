@@ -100,3 +100,92 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
             x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
     conditional_sampler.last_mechanism = mech
     return x_next, x_all, cond_images
+
+
+def conditional_sampler_batched(net, noise, measurements, operators, num_steps=18, sigma_min=None, sigma_max=None,
+                                rho=7, solver="heun", **other_args):
+    """B independent images advanced in lock-step (BASELINE.json config 2, "batch = 8"): every guidance call runs
+    ONE UNet forward and ONE UNet input-VJP over the whole batch, while the per-image Free Hunch work (covariance
+    updates, CG solve, branch) runs concurrently on one HIP stream + host thread + scratch context per image.
+    Each image keeps its own plugin instance, exactly as in `conditional_sampler`; results are identical to running
+    the images one by one up to the batch-size dependence of the UNet's floating-point summation order.
+
+    noise [B,3,S,S] float32; measurements / operators: length-B lists (operator b must carry ctx_slot = b)."""
+    from concurrent.futures import ThreadPoolExecutor
+    assert solver in ["euler", "heun"]
+    B = noise.shape[0]
+    dev = noise.device
+    sigma_min = 0.002 if sigma_min is None else sigma_min
+    sigma_max = 80 if sigma_max is None else sigma_max
+    sigma_min, sigma_max = max(sigma_min, net.sigma_min), min(sigma_max, net.sigma_max)
+    t_steps = net.round_sigma(get_sigma_steps("edm", num_steps, sigma_min, sigma_max, rho, dev))
+    t_list = [float(t) for t in t_steps] + [0.0]
+    o = other_args
+    mechs = []
+    for b in range(B):
+        assert getattr(operators[b], "ctx_slot", 0) == b, "operator b needs its own scratch context (ctx_slot = b)"
+        mechs.append(choose_conditioning_mechanism(o["conditioning_mechanism"])(
+            o["cond_scaling"], operators[b], o["clip_x0_mean"], init_denoiser_variance=1,
+            init_noise_variance=torch.tensor(t_list[0], dtype=torch.float64) ** 2, data_dim=noise.shape[1:].numel(),
+            max_vector_count=o["max_vector_count"], data_dir=o["dataset_path"],
+            image_base_covariance=o["image_base_covariance"],
+            denoiser_mean_error_threshold=o["denoiser_mean_error_threshold"],
+            use_analytical_score_time_update=o["use_analytical_score_time_update"],
+            project_to_diagonal=o["project_to_diagonal"], space_step_update_threshold=o["space_step_update_threshold"],
+            space_step_update_lower_threshold=o["space_step_update_lower_threshold"], max_rtol=o["max_rtol"],
+            do_space_updates=o["do_space_updates"], solver_type=o.get("solver_type", "customcuda")))
+    ys = [m.to(dev) for m in measurements]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
+    pool = ThreadPoolExecutor(max_workers=B)
+    device_index = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def fan_out(fn):
+        """run fn(b) for every image on its own stream/thread, then make the caller's stream wait for all of them"""
+        main = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def job(b):
+            torch.cuda.set_device(device_index)
+            with torch.cuda.stream(streams[b]):
+                streams[b].wait_event(start)
+                out = fn(b)
+                out.record_stream(main)
+                done = torch.cuda.Event()
+                done.record(streams[b])
+            return out, done
+
+        res = list(pool.map(job, range(B)))
+        for _, done in res:
+            main.wait_event(done)
+        return [r[0] for r in res]
+
+    def guidance(x, t):
+        sigma = torch.tensor(t, dtype=torch.float64, device=dev)
+        x_t = x.detach().requires_grad_()
+        with torch.enable_grad():
+            x0_mean, _ = net(x_t, sigma)
+        x_det, m_det = x_t.detach(), x0_mean.detach()
+        mats = torch.cat(fan_out(lambda b: mechs[b].fh_solve(x_det[b:b + 1], m_det[b:b + 1], ys[b], sigma, net)), 0)
+        (g,) = torch.autograd.grad((mats * x0_mean).sum(), x_t)
+        outs = fan_out(lambda b: mechs[b].fh_finish(mats[b:b + 1], g[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], sigma))
+        out = torch.cat(outs, 0)
+        return out.clip(-1, 1) if o["clip_x0_mean"] else out
+
+    x_next = noise.to(torch.float64) * t_list[0]
+    for i, (t_cur, t_next) in enumerate(zip(t_list[:-1], t_list[1:])):
+        x_hat, t_hat = x_next, t_cur  # S_churn = 0
+        h = t_next - t_hat
+        denoised = guidance(x_hat, t_hat)
+        d_cur = -(-(x_hat - denoised) / t_hat ** 2) * t_hat
+        x_prime = x_hat + h * d_cur
+        t_prime = t_hat + h
+        if solver == "euler" or i == num_steps - 1:
+            x_next = x_hat + h * d_cur
+        else:
+            denoised = guidance(x_prime, t_prime)
+            d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * denoised
+            x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
+    pool.shutdown()
+    conditional_sampler_batched.last_mechanisms = mechs
+    return x_next
