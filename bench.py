@@ -79,6 +79,7 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
                                   dtype=torch.float32))
     x = conditional_sampler_batched(net, torch.cat(noises, 0).to(device), ys, ops, num_steps=num_steps,
                                     sigma_min=0.002, sigma_max=80, rho=7, solver=solver, **fh_kwargs(data_dir, solver))
+    run_batch.cg_iters = [sum(t["niter"] for t in m.trace) for m in conditional_sampler_batched.last_mechanisms]
     return enc.decode(x)
 
 
@@ -232,7 +233,8 @@ def main():
             "config": {"workload": f"{a.arch.upper()}-256 arch, {a.operator}, FH low-rank covariance (dct_diagonal), "
                                    f"num_steps={a.num_steps} {a.solver}, batch={a.batch} per GPU",
                        "images_per_step": a.batch * world, "unet_backend": a.unet_backend,
-                       "net_calls_per_image": 2 * a.num_steps - 1 if a.solver == "heun" else a.num_steps},
+                       "net_calls_per_image": 2 * a.num_steps - 1 if a.solver == "heun" else a.num_steps,
+                       "cg_iters_per_image_last_step": getattr(run_batch, "cg_iters", None)},
         }
         line["roofline"] = roofline_cov_apply(device)
         if world == 1 and not a.no_cpu_baseline:

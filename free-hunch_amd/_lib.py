@@ -18,7 +18,8 @@ class FhProblem(C.Structure):
                 ("ntaps", C.c_int32), ("m", C.c_int32), ("ldm", C.c_int32), ("halo", C.c_int32),
                 ("d", C.c_int64), ("sigma_y2", C.c_double),
                 ("tap_dy", c_dp), ("tap_dx", c_dp), ("tap_w", c_dp), ("mask", c_dp),
-                ("D", c_dp), ("r", c_dp), ("B", c_dp), ("M", c_dp)]
+                ("D", c_dp), ("r", c_dp), ("B", c_dp), ("M", c_dp),
+                ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("tap2_dy", c_dp), ("tap2_dx", c_dp), ("tap2_w", c_dp)]
 
 
 class FhCgInfo(C.Structure):
@@ -39,7 +40,7 @@ _SIGS = {
     "fh_space_commit": ([C.c_void_p, c_dp, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,
                          c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_void_p], C.c_int),
     "fh_axpby": ([C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
-    "fh_read_scalars": ([c_dp, C.POINTER(C.c_double), C.c_int, C.c_void_p], C.c_int),
+    "fh_read_scalars": ([C.c_void_p, c_dp, C.POINTER(C.c_double), C.c_int, C.c_void_p], C.c_int),
     "fh_conv_circ": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_void_p], C.c_int),
     "fh_amm": ([C.c_void_p, C.POINTER(FhProblem), c_dp, c_dp, C.c_void_p], C.c_int),
@@ -142,7 +143,7 @@ class Context:
 
     def read_scalars(self, scal, k):
         buf = (C.c_double * k)()
-        check(self.lib.fh_read_scalars(ptr(scal), buf, k, stream()), "fh_read_scalars")
+        check(self.lib.fh_read_scalars(self.h, ptr(scal), buf, k, stream()), "fh_read_scalars")
         return list(buf)
 
     def axpby(self, alpha, a, beta, b, out):

@@ -81,6 +81,10 @@ def _problem(operator, cov, sigma_y2):
         keep.append(mask)
     else:
         t = operator.taps
+        if t.sep is not None and operator.name != "super_resolution":
+            t, t2 = t.sep
+            p.ntaps2, p.halo2 = t2.n, t2.halo
+            p.tap2_dy, p.tap2_dx, p.tap2_w = t2.dy.data_ptr(), t2.dx.data_ptr(), t2.w.data_ptr()
         p.ntaps, p.halo = t.n, t.halo
         p.tap_dy, p.tap_dx, p.tap_w = t.dy.data_ptr(), t.dx.data_ptr(), t.w.data_ptr()
     return p, keep
@@ -111,8 +115,7 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
         mask = keep[-1].view_as(x64)
         b = ctx.axpby(1.0, (mask * y64).contiguous(), -1.0, (mask * x64).contiguous(), torch.empty_like(x64))
     else:
-        ax = torch.empty_like(y64)
-        ctx.conv(x64, ax, operator.taps, 3, prob.stride, adjoint=False)
+        ax = operator._conv(x64, stride=prob.stride)
         b = ctx.axpby(1.0, y64, -1.0, ax, ax)
     sol = torch.empty_like(b)
     info = _lib.FhCgInfo()
@@ -126,9 +129,7 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
                          "rtol": rtol})
     if name == "inpainting":
         return sol
-    mat = torch.empty_like(x64)
-    ctx.conv(sol, mat, operator.taps, 3, prob.stride, adjoint=True)
-    return mat
+    return operator._conv(sol, stride=prob.stride, adjoint=True)
 
 
 def choose_solver(operator_name, operator, y, x0_mean, theta0_var=None, covariance_model=None, method="customcuda",

@@ -52,4 +52,6 @@ struct fh_context {
   // CG work vectors (n <= planes_max*S*S)
   double *cg_r, *cg_p, *cg_ap, *w0, *w1, *w2;
   fh_cg_state* cg_state;
+  fh_cg_state* h_state;  // pinned host mirror of cg_state (read back every few iterations)
+  double* h_scal;        // pinned host staging for fh_read_scalars (64 doubles)
 };

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
                                                   const int* __restrict__ done) {
   DONE_GUARD(done);
   constexpr int BM = 32, BN = 32, BK = 32, LD = BK + 2;
-  __shared__ double As[BM][LD];
-  __shared__ double Bs[BN][LD];
+  __shared__ double As[2][BM][LD];
+  __shared__ double Bs[2][BN][LD];
   A += sA * blockIdx.z;
   B += sB * blockIdx.z;
   C += sC * blockIdx.z;
@@ -45,37 +45,55 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   const int li = lane & 15, lk = lane >> 4;
   double4_t acc = {0.0, 0.0, 0.0, 0.0};
   const int srow = tid >> 3, sseg = (tid & 7) * 4;  // staging: 32 rows x 8 segments of 4 doubles
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    {
-      const int gm = m0 + srow;
+  double ra[4], rb[4];
+  auto load_chunk = [&](int k0) {  // global -> registers (issued one chunk ahead of its use)
+    const int gm = m0 + srow;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int gk = k0 + sseg + e;
-        As[srow][sseg + e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int gk = k0 + sseg + e;
+      ra[e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
     }
     if (BT) {
       const int gn = n0 + srow;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gk = k0 + sseg + e;
-        Bs[srow][sseg + e] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+        rb[e] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
       }
     } else {
       const int gk = k0 + srow;  // srow indexes k here, sseg the n segment
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gn = n0 + sseg + e;
-        Bs[sseg + e][srow] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
+        rb[e] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
       }
     }
-    __syncthreads();
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) As[buf][srow][sseg + e] = ra[e];
+    if (BT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bs[buf][srow][sseg + e] = rb[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bs[buf][sseg + e][srow] = rb[e];
+    }
+  };
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+    const bool more = k0 + BK < K;
+    if (more) load_chunk(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      const double a = As[wm + li][kk + lk];
-      const double b = Bs[wn + li][kk + lk];
+      const double a = As[buf][wm + li][kk + lk];
+      const double b = Bs[buf][wn + li][kk + lk];
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
+    if (more) store_chunk(buf ^ 1);
     __syncthreads();
   }
   const int gn = n0 + wn + li;
@@ -468,18 +486,27 @@ __global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__
 //   k_conv_direct : decimated forward (SR: out[i][j] sampled at (i*stride, j*stride)).
 // Epilogue: out = acc + add_scale * add  when add != null  (the sigma_y^2 u term of A_mm).
 // ------------------------------------------------------------------------------------------------
+constexpr int kMaxTaps = 1024;
+
 __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in, double* __restrict__ out,
                                                    const int* __restrict__ tdy, const int* __restrict__ tdx,
                                                    const double* __restrict__ tw, int ntaps, int S, int halo,
                                                    int adjoint, int up, const double* __restrict__ add,
                                                    double add_scale, const int* __restrict__ done) {
   DONE_GUARD(done);
-  extern __shared__ __align__(16) double tile[];
+  extern __shared__ __align__(16) double tile[];  // [sh*sw] tile | [ntaps] weights | [ntaps] int offsets
   const int sw = 32 + 2 * halo, sh = 16 + 2 * halo;
+  double* s_w = tile + sw * sh;
+  int* s_off = reinterpret_cast<int*>(s_w + ntaps);
   const int plane = blockIdx.z;
   const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 32;
   const int Sin = S / up;
   const double* src = in + (int64_t)plane * Sin * Sin;
+  const int sgn = adjoint ? 1 : -1;
+  for (int t = threadIdx.x; t < ntaps; t += 256) {  // taps -> LDS: the inner loop then needs no scalar-memory waits
+    s_w[t] = tw[t];
+    s_off[t] = sgn * (tdy[t] * sw + tdx[t]);
+  }
   for (int idx = threadIdx.x; idx < sw * sh; idx += 256) {
     const int ly = idx / sw, lx = idx % sw;
     int gy = (oy0 + ly - halo) % S, gx = (ox0 + lx - halo) % S;
@@ -495,15 +522,25 @@ __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in
   }
   __syncthreads();
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // ly in [0,8): rows ly, ly+8
-  const int sgn = adjoint ? 1 : -1;
   double a0 = 0, a1 = 0;
-  const int base = (ly + halo) * sw + lx + halo;
-  for (int t = 0; t < ntaps; ++t) {
-    const int off = sgn * (tdy[t] * sw + tdx[t]);
-    const double w = tw[t];
-    const double* q = tile + base + off;
-    a0 = fma(w, q[0], a0);
-    a1 = fma(w, q[8 * sw], a1);
+  const double* q0 = tile + (ly + halo) * sw + lx + halo;
+  const double* q1 = q0 + 8 * sw;
+  int t = 0;
+  for (; t + 3 < ntaps; t += 4) {
+    const int o0 = s_off[t], o1 = s_off[t + 1], o2 = s_off[t + 2], o3 = s_off[t + 3];
+    const double w0 = s_w[t], w1 = s_w[t + 1], w2 = s_w[t + 2], w3 = s_w[t + 3];
+    a0 = fma(w0, q0[o0], a0);
+    a1 = fma(w0, q1[o0], a1);
+    a0 = fma(w1, q0[o1], a0);
+    a1 = fma(w1, q1[o1], a1);
+    a0 = fma(w2, q0[o2], a0);
+    a1 = fma(w2, q1[o2], a1);
+    a0 = fma(w3, q0[o3], a0);
+    a1 = fma(w3, q1[o3], a1);
+  }
+  for (; t < ntaps; ++t) {
+    a0 = fma(s_w[t], q0[s_off[t]], a0);
+    a1 = fma(s_w[t], q1[s_off[t]], a1);
   }
   const int ox = ox0 + lx;
   if (ox >= S) return;
@@ -549,14 +586,15 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
                        const double* w, int ntaps, int halo, int planes, int stride, int adjoint, const double* add,
                        double add_scale, const int* done, hipStream_t st) {
   const int S = ctx->S;
-  if (stride < 1 || S % stride != 0 || halo < 0 || halo > 32) return FH_EINVAL;
+  if (stride < 1 || S % stride != 0 || halo < 0 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
   if (!adjoint && stride > 1) {
     const int So = S / stride;
     const int64_t total = (int64_t)planes * So * So;
     hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, dy, dx, w,
                        ntaps, S, stride, planes, add, add_scale, done);
   } else {
-    const size_t lds = (size_t)(32 + 2 * halo) * (16 + 2 * halo) * sizeof(double);
+    const size_t lds = (size_t)(32 + 2 * halo) * (16 + 2 * halo) * sizeof(double) + (size_t)ntaps * 12;
+    if (lds > 64 * 1024) return FH_ESIZE;
     dim3 grid((S + 31) / 32, (S + 15) / 16, planes);
     hipLaunchKernelGGL(k_conv_tile, grid, dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, halo, adjoint,
                        adjoint ? stride : 1, add, add_scale, done);
@@ -576,9 +614,18 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const double* u, dou
   int rc;
   double *w0 = ctx->w0, *w1 = ctx->w1;
   const int halo = p->halo;
+  const bool sep = p->ntaps2 > 0;  // separable PSF: two 1-D passes (blur only, stride 1)
+  if (sep && p->stride != 1) return FH_EINVAL;
   // w0 = A^T u
   if (p->op == 0) {
     hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, u, (const double*)nullptr, 0.0, w0, d, done);
+  } else if (sep) {
+    rc = conv_launch(ctx, u, w1, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, p->planes, 1, 1, nullptr, 0.0,
+                     done, st);
+    if (rc) return rc;
+    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, 1, 1, nullptr, 0.0, done,
+                     st);
+    if (rc) return rc;
   } else {
     rc = conv_launch(ctx, u, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 1, nullptr,
                      0.0, done, st);
@@ -600,6 +647,13 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const double* u, dou
   if (p->op == 0) {
     hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, (const double*)w1, u, p->sigma_y2, out, d,
                        done);
+  } else if (sep) {
+    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, 1, 0, nullptr, 0.0, done,
+                     st);
+    if (rc) return rc;
+    rc = conv_launch(ctx, w0, out, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, p->planes, 1, 0, u,
+                     p->sigma_y2, done, st);
+    if (rc) return rc;
   } else {
     rc = conv_launch(ctx, w1, out, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 0, u,
                      p->sigma_y2, done, st);
@@ -762,6 +816,8 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->w2, sizeof(double) * (4 * kDotBlocks + 16)));
   FH_CHECK(hipMalloc(&c->cg_state, sizeof(fh_cg_state)));
   FH_CHECK(hipMemset(c->cg_state, 0, sizeof(fh_cg_state)));
+  FH_CHECK(hipHostMalloc((void**)&c->h_state, sizeof(fh_cg_state), hipHostMallocDefault));
+  FH_CHECK(hipHostMalloc((void**)&c->h_scal, sizeof(double) * 64, hipHostMallocDefault));
   *out = c;
   return 0;
 }
@@ -772,6 +828,8 @@ int fh_context_destroy(fh_context* c) {
                   c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (c->h_state) (void)hipHostFree(c->h_state);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
   delete c;
   return 0;
 }
@@ -849,10 +907,11 @@ int fh_axpby(double alpha, const double* a, double beta, const double* b, double
   return 0;
 }
 
-int fh_read_scalars(const double* scal, double* out_host, int k, void* stream) {
-  if (!scal || !out_host || k < 1) return FH_EINVAL;
-  FH_CHECK(hipMemcpyAsync(out_host, scal, sizeof(double) * k, hipMemcpyDeviceToHost, (hipStream_t)stream));
+int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k, void* stream) {
+  if (!ctx || !scal || !out_host || k < 1 || k > 64) return FH_EINVAL;
+  FH_CHECK(hipMemcpyAsync(ctx->h_scal, scal, sizeof(double) * k, hipMemcpyDeviceToHost, (hipStream_t)stream));
   FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  memcpy(out_host, ctx->h_scal, sizeof(double) * k);
   return 0;
 }
 
@@ -885,7 +944,7 @@ int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x
   hipLaunchKernelGGL(k_cg_init, dim3(kCgBlocks), dim3(256), 0, st, b, (const double*)ap, x, r, pk, part, n);
   hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(256), 0, st, (const double*)part, kCgBlocks, rtol, atol, stt,
                      rzbuf);
-  fh_cg_state h;
+  fh_cg_state& h = *ctx->h_state;  // pinned: the periodic read-back is a true async copy
   memset(&h, 0, sizeof(h));
   int k = 0;
   const int chunk = 8;
@@ -902,7 +961,7 @@ int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x
       hipLaunchKernelGGL(k_cg_step2, dim3(kCgBlocks), dim3(256), 0, st, (const double*)r, pk,
                          (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, k, n);
     }
-    FH_CHECK(hipMemcpyAsync(&h, stt, sizeof(h), hipMemcpyDeviceToHost, st));
+    FH_CHECK(hipMemcpyAsync(ctx->h_state, stt, sizeof(fh_cg_state), hipMemcpyDeviceToHost, st));
     FH_CHECK(hipStreamSynchronize(st));
   }
   FH_LAUNCH_CHECK();

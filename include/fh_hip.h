@@ -74,8 +74,8 @@ int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double
 /* out = alpha*a + beta*b (b may be null when beta == 0); the few remaining elementwise steps of the
  * time update (mean' = x + sigma'^2 score', online_update_bfgs.py:178-180). */
 int fh_axpby(double alpha, const double* a, double beta, const double* b, double* out, int64_t n, void* stream);
-/* blocking copy of k doubles from device scratch to host (one stream sync) */
-int fh_read_scalars(const double* scal, double* out_host, int k, void* stream);
+/* blocking copy of k <= 64 doubles from device scratch to host through the context's pinned buffer (one stream sync) */
+int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k, void* stream);
 
 /* measurement operators, measurement_utils/measurements.py:87-246 + utils_sisr.py:44-96 ----------
  * Circular 2-D convolution with a sparse tap list (the PSF non-zeros, centre at kernel_size/2):
@@ -108,6 +108,12 @@ typedef struct fh_problem {
   const double* r;
   const double* B;
   const double* M;
+  /* optional second pass of a separable PSF (k = col (x) row): A = conv(tap2) o conv(tap), ntaps2 = 0 when unused */
+  int32_t ntaps2;
+  int32_t halo2;
+  const int32_t* tap2_dy;
+  const int32_t* tap2_dx;
+  const double* tap2_w;
 } fh_problem;
 
 typedef struct fh_cg_info {
