@@ -1,6 +1,6 @@
 """__graft_entry__.smoke(): one small invocation of the hot path on cuda:0, checked against the CPU oracle.
 
-A 64x64 super-resolution Free Hunch run (Heun, 4 steps = 7 guidance calls: UNet forward + input-VJP, covariance
+A 64x64 super-resolution Free Hunch run (Heun, 10 steps = 19 guidance calls: UNet forward + input-VJP, covariance
 time/space updates, CG solves through the operator) with the product on the GPU, against the oracle on the host."""
 import os
 import sys
@@ -49,16 +49,16 @@ def run():
 
     fac = lambda op_, v0, d: fo.OracleFreeHunch(1.0, op_, False, v0, d, image_base_covariance="dct_diagonal",
                                                 data_dir=tmp)
-    xo, mo = fo.conditional_sampler(onet, noise, y, oop, num_steps=4, solver="heun", mechanism_factory=fac)
+    xo, mo = fo.conditional_sampler(onet, noise, y, oop, num_steps=10, solver="heun", mechanism_factory=fac)
     xh, _, _ = conditional_sampler(
-        hnet, noise.to(dev), None, None, num_steps=4, sigma_min=0.002, sigma_max=80, rho=7, solver="heun",
+        hnet, noise.to(dev), None, None, num_steps=10, sigma_min=0.002, sigma_max=80, rho=7, solver="heun",
         measurement=y.to(dev), operator=hop, conditioning_mechanism="online_covariance", cond_scaling=1.0,
         clip_x0_mean=False, max_vector_count=100000, dataset_path=tmp, image_base_covariance="dct_diagonal",
         denoiser_mean_error_threshold=0.2, use_analytical_score_time_update=True, project_to_diagonal=False,
         space_step_update_threshold=10.0, space_step_update_lower_threshold=1.0, max_rtol=1.0, do_space_updates=True)
     mh = conditional_sampler.last_mechanism
     err = float((xh.cpu() - xo).abs().max())
-    print(f"smoke: 64x64 SR Heun-4, {len(mh.trace)} guidance calls, CG iters {[t['niter'] for t in mh.trace]} "
+    print(f"smoke: 64x64 SR Heun-10, {len(mh.trace)} guidance calls, CG iters {[t['niter'] for t in mh.trace]} "
           f"(oracle {[t['niter'] for t in mo.trace]}), k={mh.trace[-1]['k']}, max|x_hip - x_oracle| = {err:.3e}")
     assert [t["k"] for t in mh.trace] == [t["k"] for t in mo.trace]
     assert err < 1e-3, err

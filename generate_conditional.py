@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Free Hunch conditional generation on MI355X - the CLI of the reference (generate_conditional.py:434-598):
+
+    python generate_conditional.py --outdir=DIR [--key=value ...]
+    torchrun --nproc-per-node 8 generate_conditional.py --outdir=DIR ...
+
+Same flags (free-hunch_amd/config.py), same outputs: DIR/images/{idx:06d}_{seed:06d}.png, cond_images/,
+forward_images/, results.txt.  Differences by design: images are sharded i -> rank i mod world with no per-image
+barrier, each rank runs `max_batch_size` images in lock-step, outputs are exchanged with one all_gather at the end,
+RNG is keyed by (seed, image index).  LPIPS needs a network download and is omitted; PSNR is computed on device.
+`--synthetic_weights=ffhq|imagenet` runs with seeded random weights when no checkpoint is present."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main(argv=None):
+    from free_hunch_amd import unet as hu
+    from free_hunch_amd.config import load_config
+    from free_hunch_amd.measurements import get_operator
+    from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, psnr_u8, shard_indices
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
+
+    o = load_config(argv)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if o.conditioning_mechanism != "online_covariance":
+        raise NotImplementedError("only the Free Hunch plugin ('online_covariance') is implemented on MI355X")
+    if o.iddpm_preconditioning != "linear":
+        raise NotImplementedError("cosine preconditioning is incompatible with the plugin API in the reference too")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    os.makedirs(o.outdir, exist_ok=True)
+
+    if o.synthetic_weights:
+        cfg = {"ffhq": hu.FFHQ256, "imagenet": hu.IMAGENET256}[o.synthetic_weights]
+        model = hu.UNetModel(cfg, backend=o.unet_backend)
+        model.load_state_dict(hu.seeded_state(cfg, 0))
+    else:
+        model, cfg = hu.load_model(o.openai_state_dict_path, o.openai_setup_path, backend=o.unet_backend)
+    net = iDDPMLinearPrecond(model.to(device).eval(), cfg.image_size, 3).to(device)
+    S = cfg.image_size
+
+    files = list_images(o.dataset_path)[: o.total_images]
+    if not files:
+        raise SystemExit(f"no images under {o.dataset_path}")
+    total = len(files)
+    mine = shard_indices(total, rank, world)
+    enc = StandardRGBEncoder()
+    kw = dict(conditioning_mechanism=o.conditioning_mechanism, cond_scaling=o.cond_scaling, clip_x0_mean=o.clip_x0_mean,
+              max_vector_count=o.max_vector_count, dataset_path=os.path.join(ROOT, "free-hunch_amd", "data")
+              if not os.path.exists(os.path.join(o.dataset_path, "dct_variance.pt")) else o.dataset_path,
+              image_base_covariance=o.image_base_covariance,
+              denoiser_mean_error_threshold=o.denoiser_mean_error_threshold,
+              use_analytical_score_time_update=o.use_analytical_score_time_update,
+              project_to_diagonal=o.project_to_diagonal, space_step_update_threshold=o.space_step_update_threshold,
+              space_step_update_lower_threshold=o.space_step_update_lower_threshold, max_rtol=o.max_rtol,
+              do_space_updates=o.do_space_updates, solver_type=o.solver_type)
+    outs, conds, fwds = [], [], []
+    seed = o.seeds[0]
+    for s in range(0, len(mine), o.max_batch_size):
+        idxs = mine[s: s + o.max_batch_size]
+        ops, ys, noise, imgs = [], [], [], []
+        for b, i in enumerate(idxs):
+            key = (seed * 1000003 + i) % (1 << 31)  # RNG keyed by (seed, image index): independent of the world size
+            np.random.seed(key)
+            torch.manual_seed(key)
+            op = get_operator(name=o.operator_name, device=device, sigma_s=o.noise_sigma, kernel_size=o.kernel_size,
+                              intensity=o.intensity, scale_factor=o.scale_factor, in_shape=(1, 3, S, S),
+                              mask_opt={"mask_type": o.inpainting_type, "mask_len_range": (64, 156),
+                                        "mask_prob_range": (o.inpainting_prob_lower, o.inpainting_prob_upper),
+                                        "image_size": S})
+            op.ctx_slot = b
+            img = load_image_u8(files[i], S)
+            imgs.append(img)
+            ops.append(op)
+            ys.append(op.forward(enc.encode(img[None].to(device)), noiseless=False))
+            noise.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(key), dtype=torch.float32))
+        x = conditional_sampler_batched(net, torch.cat(noise).to(device), ys, ops, num_steps=o.num_steps,
+                                        sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver, **kw)
+        outs.append(enc.decode(x))
+        conds.append(torch.stack(imgs).to(device))
+        fwds += [enc.decode(y) for y in ys]
+        print(f"[rank {rank}] images {idxs} done", flush=True)
+    local_out = torch.cat(outs) if outs else torch.zeros((0, 3, S, S), dtype=torch.uint8, device=device)
+    local_cond = torch.cat(conds) if conds else torch.zeros((0, 3, S, S), dtype=torch.uint8, device=device)
+    all_out = gather_images(local_out, mine, total, device)   # the single exchange of the run
+    all_cond = gather_images(local_cond, mine, total, device)
+    if rank == 0:
+        import PIL.Image
+        for sub in ("images", "cond_images", "forward_images"):
+            os.makedirs(os.path.join(o.outdir, sub), exist_ok=True)
+        for i in range(total):
+            name = f"{i:06d}_{seed:06d}.png"
+            PIL.Image.fromarray(all_out[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(os.path.join(o.outdir, "images", name))
+            PIL.Image.fromarray(all_cond[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(
+                os.path.join(o.outdir, "cond_images", name))
+        psnr = psnr_u8(all_out, all_cond)
+        with open(os.path.join(o.outdir, "results.txt"), "w") as f:
+            f.write(f"PSNR: {float(psnr.mean()):.4f}\nimages: {total}\n")
+        print(f"PSNR {float(psnr.mean()):.3f} dB over {total} images -> {o.outdir}", flush=True)
+    for j, i in enumerate(mine):  # forward (measurement) images are written by the owning rank
+        if fwds[j].shape[-1] == S:
+            import PIL.Image
+            os.makedirs(os.path.join(o.outdir, "forward_images"), exist_ok=True)
+            PIL.Image.fromarray(fwds[j][0].permute(1, 2, 0).cpu().numpy(), "RGB").save(
+                os.path.join(o.outdir, "forward_images", f"{i:06d}_{seed:06d}.png"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
