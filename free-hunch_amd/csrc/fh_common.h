@@ -48,7 +48,8 @@ struct fh_context {
   double* partial;    // [kPartialRows][FH_MAX_COLS] block partials (dots) / scalar partials
   double* gpartial;   // Gram partials
   int64_t gpartial_elems;
-  double* coef;       // [2*FH_MAX_COLS] t and M t
+  double* coef;       // [2][FH_MAX_COLS] double-buffered t = B^T (r.*z)
+  int t_parity;       // which half the next apply accumulates into
   // CG work vectors (n <= planes_max*S*S)
   double *cg_r, *cg_p, *cg_ap, *w0, *w1, *w2;
   fh_cg_state* cg_state;

