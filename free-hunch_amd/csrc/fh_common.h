@@ -37,7 +37,19 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 
 struct fh_cg_state {  // device-resident control block of the CG loop
   double rz, pAp, rnorm, stop, bnorm;
-  int done, niter, optimal, pad;
+  int done;      // 0 running, 1 converged (optimal), 2 pAp <= 1e-16, 3 maxiter reached
+  int niter, optimal;
+  int it;        // completed iterations (device-side loop counter: the iteration body is graph-replayable)
+  int k_cur;     // iteration in flight, written by step 1, consumed by step 2
+  int maxiter;
+};
+
+struct fh_graph_entry {  // one instantiated chunk-of-iterations graph, keyed by the problem it was captured for
+  fh_problem key;
+  int64_t n;
+  hipGraphExec_t exec;
+  hipGraph_t graph;
+  uint64_t stamp;
 };
 
 struct fh_context {
@@ -55,4 +67,8 @@ struct fh_context {
   fh_cg_state* cg_state;
   fh_cg_state* h_state;  // pinned host mirror of cg_state (read back every few iterations)
   double* h_scal;        // pinned host staging for fh_read_scalars (64 doubles)
+  double* cg_x;          // CG iterate (the caller's x is written once at the end)
+  fh_graph_entry graphs[4];
+  uint64_t graph_clock;
+  int graphs_disabled;   // set when stream capture is not possible on the caller's stream (e.g. the null stream)
 };

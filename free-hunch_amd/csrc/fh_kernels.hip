@@ -7,6 +7,7 @@
 // returns at once when it is set, which lets the host enqueue iterations in chunks without changing
 // the reference's stopping rule.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, c
 }
 
 __global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ part, int nparts, double rtol,
-                                                     double atol, fh_cg_state* __restrict__ stt,
+                                                     double atol, int maxiter, fh_cg_state* __restrict__ stt,
                                                      double* __restrict__ rzbuf) {
   __shared__ double red[4];
   const double srr = sum_partials(part, nparts, red);
@@ -722,6 +723,9 @@ __global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ 
     stt->done = 0;
     stt->niter = 0;
     stt->optimal = 0;
+    stt->it = 0;
+    stt->k_cur = 0;
+    stt->maxiter = maxiter;
   }
 }
 
@@ -730,8 +734,13 @@ __global__ __launch_bounds__(256) void k_cg_step1(const double* __restrict__ p, 
                                                   double* __restrict__ x, double* __restrict__ r,
                                                   const double* __restrict__ part_pap, int nparts,
                                                   double* __restrict__ part_rr, const double* __restrict__ rzbuf,
-                                                  fh_cg_state* __restrict__ stt, int k, int64_t n) {
+                                                  fh_cg_state* __restrict__ stt, int64_t n) {
   if (stt->done) return;
+  const int it = stt->it, k = it + 1;
+  if (it >= stt->maxiter) {  // cg.py:245 loop bound; the host reports niter = maxiter
+    if (blockIdx.x == 0 && threadIdx.x == 0) stt->done = 3;
+    return;
+  }
   __shared__ double red[4];
   const double pAp = sum_partials(part_pap, nparts, red);
   if (pAp <= 1e-16) {  // cg.py:250 - also catches NaN-free breakdowns; x, r keep their previous values
@@ -752,14 +761,16 @@ __global__ __launch_bounds__(256) void k_cg_step1(const double* __restrict__ p, 
   }
   srr = block_sum_256(srr, red);
   if (threadIdx.x == 0) part_rr[blockIdx.x] = srr;
+  if (blockIdx.x == 0 && threadIdx.x == 0) stt->k_cur = k;
 }
 
 // iteration k, second half: stopping test, p = r + beta p
 __global__ __launch_bounds__(256) void k_cg_step2(const double* __restrict__ r, double* __restrict__ p,
                                                   const double* __restrict__ part_rr, int nparts,
-                                                  double* __restrict__ rzbuf, fh_cg_state* __restrict__ stt, int k,
+                                                  double* __restrict__ rzbuf, fh_cg_state* __restrict__ stt,
                                                   int64_t n) {
   if (stt->done) return;
+  const int k = stt->k_cur;
   __shared__ double red[4];
   const double rz_new = sum_partials(part_rr, nparts, red);
   const double rnorm = sqrt(rz_new);
@@ -779,6 +790,7 @@ __global__ __launch_bounds__(256) void k_cg_step2(const double* __restrict__ r, 
     rzbuf[k & 1] = rz_new;
     stt->rnorm = rnorm;
     stt->niter = k;
+    stt->it = k;
   }
 }
 
@@ -822,6 +834,7 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->cg_r, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->cg_p, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->cg_ap, sizeof(double) * nimg));
+  FH_CHECK(hipMalloc(&c->cg_x, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->w0, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->w1, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->w2, sizeof(double) * (4 * kDotBlocks + 16)));
@@ -839,6 +852,12 @@ int fh_context_destroy(fh_context* c) {
                   c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (auto& g : c->graphs)
+    if (g.exec) {
+      (void)hipGraphExecDestroy(g.exec);
+      (void)hipGraphDestroy(g.graph);
+    }
+  if (c->cg_x) (void)hipFree(c->cg_x);
   if (c->h_state) (void)hipHostFree(c->h_state);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   delete c;
@@ -938,6 +957,75 @@ int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, v
   return amm_launch(ctx, p, u, out, nullptr, (hipStream_t)stream);
 }
 
+// One chunk of CG iterations, enqueued on `st` (eagerly, or while the stream is being captured into a graph).
+static int cg_enqueue_chunk(fh_context* ctx, const fh_problem* p, int64_t n, int count, hipStream_t st) {
+  double *x = ctx->cg_x, *r = ctx->cg_r, *pk = ctx->cg_p, *ap = ctx->cg_ap;
+  double* part = ctx->w2;
+  double* rzbuf = ctx->w2 + 4 * kDotBlocks;
+  fh_cg_state* stt = ctx->cg_state;
+  const int* done = &stt->done;
+  for (int i = 0; i < count; ++i) {
+    int rc = amm_launch(ctx, p, pk, ap, done, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_dot_partial, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap,
+                       (const double*)nullptr, (const double*)nullptr, part, n, done);
+    hipLaunchKernelGGL(k_cg_step1, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
+                       (const double*)part, kCgBlocks, part + 2 * kDotBlocks, (const double*)rzbuf, stt, n);
+    hipLaunchKernelGGL(k_cg_step2, dim3(kCgBlocks), dim3(256), 0, st, (const double*)r, pk,
+                       (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, n);
+  }
+  return 0;
+}
+
+// The iteration body depends on device state only (counter, scalars, done flag), so a chunk is captured once per
+// (problem, pointers, m) into a hipGraph and replayed: one host call per 8 iterations instead of ~110 launches.
+static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, int64_t n, int chunk, hipStream_t st) {
+  if (ctx->graphs_disabled) return nullptr;
+  if (getenv("FH_NO_GRAPH") != nullptr) return nullptr;  // A/B switch for profiling
+  ++ctx->graph_clock;
+  fh_graph_entry* slot = &ctx->graphs[0];
+  for (auto& g : ctx->graphs) {
+    if (g.exec != nullptr && g.n == n && memcmp(&g.key, p, sizeof(fh_problem)) == 0) {
+      g.stamp = ctx->graph_clock;
+      return g.exec;
+    }
+    if (g.stamp < slot->stamp) slot = &g;
+  }
+  if (slot->exec != nullptr) {
+    (void)hipGraphExecDestroy(slot->exec);
+    (void)hipGraphDestroy(slot->graph);
+    slot->exec = nullptr;
+  }
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->graphs_disabled = 1;  // e.g. the legacy null stream: stay on eager launches
+    return nullptr;
+  }
+  // t_parity etc. are not involved; the enqueue only records launches
+  const int rc = cg_enqueue_chunk(ctx, p, n, chunk, st);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != 0 || e != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    ctx->graphs_disabled = 1;
+    return nullptr;
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(graph);
+    ctx->graphs_disabled = 1;
+    return nullptr;
+  }
+  memcpy(&slot->key, p, sizeof(fh_problem));
+  slot->n = n;
+  slot->exec = exec;
+  slot->graph = graph;
+  slot->stamp = ctx->graph_clock;
+  return exec;
+}
+
 int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
                 int maxiter, fh_cg_info* info, void* stream) {
   if (!ctx || !p || !b || !x || !info || maxiter < 1 || !(rtol > 0 || atol > 0)) return FH_EINVAL;
@@ -949,34 +1037,28 @@ int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x
   double* part = ctx->w2;                      // [0,256) pAp / init r.r ; [256,512) init b.b ; [512,768) r.r
   double* rzbuf = ctx->w2 + 4 * kDotBlocks;    // [2]
   fh_cg_state* stt = ctx->cg_state;
-  const int* done = &stt->done;
   int rc = amm_launch(ctx, p, b, ap, nullptr, st);  // A x0 with x0 = b
   if (rc) return rc;
-  hipLaunchKernelGGL(k_cg_init, dim3(kCgBlocks), dim3(256), 0, st, b, (const double*)ap, x, r, pk, part, n);
-  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(256), 0, st, (const double*)part, kCgBlocks, rtol, atol, stt,
-                     rzbuf);
+  hipLaunchKernelGGL(k_cg_init, dim3(kCgBlocks), dim3(256), 0, st, b, (const double*)ap, ctx->cg_x, r, pk, part, n);
+  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(256), 0, st, (const double*)part, kCgBlocks, rtol, atol, maxiter,
+                     stt, rzbuf);
+  const int chunk = 8;
+  hipGraphExec_t exec = cg_graph_for(ctx, p, n, chunk, st);
   fh_cg_state& h = *ctx->h_state;  // pinned: the periodic read-back is a true async copy
   memset(&h, 0, sizeof(h));
-  int k = 0;
-  const int chunk = 8;
-  while (k < maxiter && !h.done) {
-    const int kend = k + chunk < maxiter ? k + chunk : maxiter;
-    for (; k < kend;) {
-      ++k;
-      rc = amm_launch(ctx, p, pk, ap, done, st);
+  for (int launched = 0; launched < maxiter + chunk && !h.done; launched += chunk) {
+    if (exec != nullptr) {
+      FH_CHECK(hipGraphLaunch(exec, st));
+    } else {
+      rc = cg_enqueue_chunk(ctx, p, n, chunk, st);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_dot_partial, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap,
-                         (const double*)nullptr, (const double*)nullptr, part, n, done);
-      hipLaunchKernelGGL(k_cg_step1, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
-                         (const double*)part, kCgBlocks, part + 2 * kDotBlocks, (const double*)rzbuf, stt, k, n);
-      hipLaunchKernelGGL(k_cg_step2, dim3(kCgBlocks), dim3(256), 0, st, (const double*)r, pk,
-                         (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, k, n);
     }
     FH_CHECK(hipMemcpyAsync(ctx->h_state, stt, sizeof(fh_cg_state), hipMemcpyDeviceToHost, st));
     FH_CHECK(hipStreamSynchronize(st));
   }
+  FH_CHECK(hipMemcpyAsync(x, ctx->cg_x, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
   FH_LAUNCH_CHECK();
-  info->niter = h.done ? h.niter : maxiter;
+  info->niter = (h.done == 1 || h.done == 2) ? h.niter : maxiter;
   info->optimal = h.optimal;
   info->residual_norm = h.rnorm;
   info->b_norm = h.bnorm;

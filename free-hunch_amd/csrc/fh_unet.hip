@@ -561,30 +561,13 @@ int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
   return 0;
 }
 
-static double* gn_scratch(int N, int nchunks, hipStream_t st) {
-  // per-device scratch for the chunk partials (grown on demand, outside any timed region after warm-up)
-  static double* buf[16] = {nullptr};
-  static size_t cap[16] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const size_t need = (size_t)N * nchunks * 64 * sizeof(double);
-  if (need > cap[dev & 15]) {
-    if (buf[dev & 15]) {
-      (void)hipStreamSynchronize(st);
-      (void)hipFree(buf[dev & 15]);
-    }
-    if (hipMalloc(&buf[dev & 15], need * 2) != hipSuccess) return nullptr;
-    cap[dev & 15] = need * 2;
-  }
-  return buf[dev & 15];
-}
+int64_t fh_groupnorm_scratch_doubles(int N, int P) { return (int64_t)N * ((P + kGnChunk - 1) / kGnChunk) * 64; }
 
-int fh_groupnorm_stats(const float* x, float* stats, int N, int P, int C, void* stream) {
-  if (!x || !stats || C % 32 != 0) return FH_EINVAL;
+int fh_groupnorm_stats(const float* x, float* stats, double* scratch, int N, int P, int C, void* stream) {
+  if (!x || !stats || !scratch || C % 32 != 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
-  double* part = gn_scratch(N, nchunks, st);
-  if (!part) return (int)hipErrorOutOfMemory;
+  double* part = scratch;
   hipLaunchKernelGGL(k_gn_partial<0>, dim3(N * nchunks), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0, part, P, C, 0, nchunks);
@@ -605,14 +588,13 @@ int fh_groupnorm_apply(const float* x, const float* stats, const float* gamma, c
 }
 
 int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
-                     const float* scale, const float* shift, int ss_stride, float* sums, float* dx, int N, int P, int C,
-                     int act, int accumulate, void* stream) {
-  if (!x || !dy || !stats || !gamma || !beta || !sums || !dx || C % 32 != 0) return FH_EINVAL;
+                     const float* scale, const float* shift, int ss_stride, float* sums, double* scratch, float* dx, int N,
+                     int P, int C, int act, int accumulate, void* stream) {
+  if (!x || !dy || !stats || !gamma || !beta || !sums || !scratch || !dx || C % 32 != 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)N * P * C;
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
-  double* part = gn_scratch(N, nchunks, st);
-  if (!part) return (int)hipErrorOutOfMemory;
+  double* part = scratch;
   hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
                      ss_stride, part, P, C, act, nchunks);
   hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(64), 0, st, (const double*)part, sums, nchunks,

@@ -103,14 +103,15 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
 
 
 def conditional_sampler_batched(net, noise, measurements, operators, num_steps=18, sigma_min=None, sigma_max=None,
-                                rho=7, solver="heun", **other_args):
+                                rho=7, solver="heun", slot_base=0, **other_args):
     """B independent images advanced in lock-step (BASELINE.json config 2, "batch = 8"): every guidance call runs
     ONE UNet forward and ONE UNet input-VJP over the whole batch, while the per-image Free Hunch work (covariance
     updates, CG solve, branch) runs concurrently on one HIP stream + host thread + scratch context per image.
     Each image keeps its own plugin instance, exactly as in `conditional_sampler`; results are identical to running
     the images one by one up to the batch-size dependence of the UNet's floating-point summation order.
 
-    noise [B,3,S,S] float32; measurements / operators: length-B lists (operator b must carry ctx_slot = b)."""
+    noise [B,3,S,S] float32; measurements / operators: length-B lists (operator b must carry ctx_slot = slot_base + b;
+    several calls may run concurrently from different host threads with disjoint slot ranges)."""
     from concurrent.futures import ThreadPoolExecutor
     assert solver in ["euler", "heun"]
     B = noise.shape[0]
@@ -123,7 +124,7 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
     o = other_args
     mechs = []
     for b in range(B):
-        assert getattr(operators[b], "ctx_slot", 0) == b, "operator b needs its own scratch context (ctx_slot = b)"
+        assert getattr(operators[b], "ctx_slot", 0) == slot_base + b, "every concurrent image needs its own ctx_slot"
         mechs.append(choose_conditioning_mechanism(o["conditioning_mechanism"])(
             o["cond_scaling"], operators[b], o["clip_x0_mean"], init_denoiser_variance=1,
             init_noise_variance=torch.tensor(t_list[0], dtype=torch.float64) ** 2, data_dim=noise.shape[1:].numel(),
@@ -160,16 +161,31 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             main.wait_event(done)
         return [r[0] for r in res]
 
+    import os as _os
+    import time as _time
+    prof = {"fwd": 0.0, "solve": 0.0, "vjp": 0.0, "finish": 0.0} if _os.environ.get("FH_PHASE_TIMES") else None
+
+    def _tick(name, t0):
+        if prof is not None:
+            torch.cuda.synchronize()
+            prof[name] += _time.perf_counter() - t0
+        return _time.perf_counter()
+
     def guidance(x, t):
         sigma = torch.tensor(t, dtype=torch.float64, device=dev)
+        t0 = _tick("finish", _time.perf_counter()) if prof is not None else 0.0
         x_t = x.detach().requires_grad_()
         with torch.enable_grad():
             x0_mean, _ = net(x_t, sigma)
+        t0 = _tick("fwd", t0)
         x_det, m_det = x_t.detach(), x0_mean.detach()
         mats = torch.cat(fan_out(lambda b: mechs[b].fh_solve(x_det[b:b + 1], m_det[b:b + 1], ys[b], sigma, net)), 0)
+        t0 = _tick("solve", t0)
         (g,) = torch.autograd.grad((mats * x0_mean).sum(), x_t)
+        t0 = _tick("vjp", t0)
         outs = fan_out(lambda b: mechs[b].fh_finish(mats[b:b + 1], g[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], sigma))
         out = torch.cat(outs, 0)
+        _tick("finish", t0)
         return out.clip(-1, 1) if o["clip_x0_mean"] else out
 
     x_next = noise.to(torch.float64) * t_list[0]
@@ -187,5 +203,13 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * denoised
             x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
     pool.shutdown()
+    if prof is not None:
+        print("[FH_PHASE_TIMES] seconds per batch:", {k: round(v, 3) for k, v in prof.items()}, flush=True)
     conditional_sampler_batched.last_mechanisms = mechs
+    conditional_sampler_batched.tls.mechanisms = mechs  # per host thread (several groups may run concurrently)
     return x_next
+
+
+import threading as _threading  # noqa: E402
+
+conditional_sampler_batched.tls = _threading.local()

@@ -217,7 +217,7 @@ class _TorchOps:
         a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, T)
         return (xf + F.conv1d(a, P[p + ".proj_out.weight"], P[p + ".proj_out.bias"])).reshape(b, c, hh, ww)
 
-    def run(self, steps, x, emb):
+    def run(self, steps, x, emb, emb_key=None):
         cfg, h, stack = self.cfg, x, []
         for op, p, _ci, _co, heads in steps:
             if op == "push":
@@ -308,9 +308,7 @@ class UNetModel(torch.nn.Module):
             if len(self._emb) > 4096:
                 self._emb.clear()
             self._emb[key] = emb
-        if hasattr(ops, "emb_key"):
-            ops.emb_key = key
-        return ops.run(self.steps, x.float(), emb)
+        return ops.run(self.steps, x.float(), emb, key)
 
 
 def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,

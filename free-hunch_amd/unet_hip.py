@@ -13,6 +13,7 @@ of 32 where they are the GEMM K dimension).
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -51,7 +52,7 @@ class HipOps:
                 name = k[: -len(".weight")]
                 self.conv[name] = _Conv(v.detach(), P[name + ".bias"].detach())
         self._emb_cache = {}
-        self.emb_key = None  # set by UNetModel.forward: the timestep tuple the embeddings depend on
+        self._tls = threading.local()  # emb_key: the timestep tuple of the call running on THIS host thread
 
     # ---------------------------------------------------------------- kernel wrappers
     def _conv(self, name, x, res=None, bias_override=None):
@@ -84,7 +85,9 @@ class HipOps:
         stats = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         st = _lib.stream()
-        _lib.check(self.lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), N, H * W, C, st), "gn_stats")
+        scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
+        _lib.check(self.lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, C, st),
+                   "gn_stats")
         ss = 0 if scale is None else scale.stride(0)
         _lib.check(self.lib.fh_groupnorm_apply(
             x.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(), self.P[name + ".bias"].data_ptr(),
@@ -95,12 +98,14 @@ class HipOps:
     def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None):
         N, H, W, C = x.shape
         sums = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
+        scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
         dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
         ss = 0 if scale is None else scale.stride(0)
         _lib.check(self.lib.fh_groupnorm_bwd(
             x.data_ptr(), dy.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(),
             self.P[name + ".bias"].data_ptr(), None if scale is None else scale.data_ptr(),
-            None if shift is None else shift.data_ptr(), ss, sums.data_ptr(), dx.data_ptr(), N, H * W, C, int(act),
+            None if shift is None else shift.data_ptr(), ss, sums.data_ptr(), scratch.data_ptr(), dx.data_ptr(), N, H * W, C,
+            int(act),
             int(accumulate_into is not None), _lib.stream()), "gn_bwd")
         return dx
 
@@ -123,12 +128,13 @@ class HipOps:
 
     # ---------------------------------------------------------------- timestep-embedding MLPs (depend on sigma only)
     def emb_out(self, prefix, emb):
-        key = (self.emb_key, prefix)
-        e = self._emb_cache.get(key) if self.emb_key is not None else None
+        ek = getattr(self._tls, "emb_key", None)
+        key = (ek, prefix)
+        e = self._emb_cache.get(key) if ek is not None else None
         if e is None:
             e = F.linear(F.silu(emb), self.P[prefix + ".emb_layers.1.weight"], self.P[prefix + ".emb_layers.1.bias"])
             e = e.float().contiguous()
-            if self.emb_key is not None:
+            if ek is not None:
                 if len(self._emb_cache) > 4096:
                     self._emb_cache.clear()
                 self._emb_cache[key] = e
@@ -301,7 +307,8 @@ class HipOps:
         _lib.check(self.lib.fh_layout_nchw_nhwc(g.data_ptr(), out.data_ptr(), N, ci, H * W, ci, 0, st), "layout")
         return out
 
-    def run(self, steps, x, emb):
+    def run(self, steps, x, emb, emb_key=None):
+        self._tls.emb_key = emb_key
         return _UNetFn.apply(x, self, steps, emb)
 
 

@@ -156,13 +156,14 @@ int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
 /* GroupNorm with 32 groups, eps = 1e-5, over x [N][P][C]:  stats [N][32][2] = (mean, rstd);
  * y = act(((x - mean) * rstd * gamma + beta) * (1 + scale[n][c]) + shift[n][c]);  scale/shift may be null;
  * scale[n] starts at scale + n * ss_stride;  act: 0 identity, 1 SiLU.
- * bwd: dx (+)= d/dx of the above applied to dy; sums is [N][32][2] scratch. */
-int fh_groupnorm_stats(const float* x, float* stats, int N, int P, int C, void* stream);
+ * bwd: dx (+)= d/dx of the above applied to dy; sums is [N][32][2] scratch; `scratch` is caller-owned workspace. */
+int64_t fh_groupnorm_scratch_doubles(int N, int P); /* size of `scratch` (float64 chunk partials) for the calls below */
+int fh_groupnorm_stats(const float* x, float* stats, double* scratch, int N, int P, int C, void* stream);
 int fh_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* scale,
                        const float* shift, int ss_stride, float* y, int N, int P, int C, int act, void* stream);
 int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
-                     const float* scale, const float* shift, int ss_stride, float* sums, float* dx, int N, int P, int C,
-                     int act, int accumulate, void* stream);
+                     const float* scale, const float* shift, int ss_stride, float* sums, double* scratch, float* dx, int N,
+                     int P, int C, int act, int accumulate, void* stream);
 
 /* in-place row softmax of s [rows][T];  backward in place on dp: dp <- p .* (dp - rowsum(dp .* p)) */
 int fh_softmax_rows(float* s, int64_t rows, int T, void* stream);

@@ -87,13 +87,14 @@ def test_groupnorm_fwd_bwd_vs_torch(dev, act, ss):
     y, dx = torch.empty_like(xn), torch.empty_like(xn)
     sc, sh = (e[:, :C], e[:, C:]) if ss else (None, None)
     st = L.stream()
-    L.check(lib.fh_groupnorm_stats(xn.data_ptr(), stats.data_ptr(), N, H * W, C, st), "stats")
+    scratch = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
+    L.check(lib.fh_groupnorm_stats(xn.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, C, st), "stats")
     L.check(lib.fh_groupnorm_apply(xn.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                    sc.data_ptr() if ss else None, sh.data_ptr() if ss else None, 2 * C, y.data_ptr(), N,
                                    H * W, C, act, st), "apply")
     L.check(lib.fh_groupnorm_bwd(xn.data_ptr(), dyn.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                  sc.data_ptr() if ss else None, sh.data_ptr() if ss else None, 2 * C, sums.data_ptr(),
-                                 dx.data_ptr(), N, H * W, C, act, 0, st), "bwd")
+                                 scratch.data_ptr(), dx.data_ptr(), N, H * W, C, act, 0, st), "bwd")
     assert rel(y.permute(0, 3, 1, 2), ref.detach()) < 2e-5
     assert rel(dx.permute(0, 3, 1, 2), gref) < 5e-5
 
