@@ -138,9 +138,14 @@ def roofline_cov_apply(device, m=32, iters=200):
     sec = e0.elapsed_time(e1) / 1e3 / iters
     algo_bytes = 8 * d * m + 8 * d * 4  # base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
+    traffic = None  # HBM-side bytes per apply from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
+    pmc = os.path.join(ROOT, "profiles", "r01_cov_apply_pmc.json")
+    if m == 32 and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get("traffic_bytes_per_apply")
     return {"bound": "hbm", "kernel": "fh_rep_apply = k_rep_dots + k_rep_coef + k_rep_apply2 (d=196608, m=32, f64)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
 
 
