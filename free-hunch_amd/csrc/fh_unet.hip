@@ -239,7 +239,12 @@ __global__ __launch_bounds__(256) void k_bgemm(GemmArgs g) {
 //   k_gn_apply : y = act( ((x - mean) * rstd * gamma + beta) * (1 + scale[n][c]) + shift[n][c] ),  act = SiLU or id
 //   k_gn_bwd_* : dx given dy (through act, scale/shift, affine and the normalisation)
 // ------------------------------------------------------------------------------------------------
-constexpr int kGnChunk = 512;  // pixels per workgroup in the statistics passes
+// pixels per workgroup in the GroupNorm passes: 512, halved until the launch has >= 256 workgroups (min 32)
+static inline int gn_chunk(int N, int P) {
+  int c = 512;
+  while (c > 32 && (int64_t)N * ((P + c - 1) / c) < 256) c >>= 1;
+  return c;
+}
 
 // Shared skeleton of the two statistics passes.  Workgroup = (image n, chunk of kGnChunk pixels); a thread owns one
 // float4 of channels (fixed over its pixel loop), accumulates two double sums per channel, folds them into 32 group
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, int ss_stride,
-                                                    double* __restrict__ partial, int P, int C, int act, int nchunks) {
+                                                    double* __restrict__ partial, int P, int C, int act, int nchunks,
+                                                    int kGnChunk) {
   __shared__ double acc[64];
   const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   const int cg = C / 32, c4n = C / 4;
@@ -275,31 +281,43 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
           mean[e] = stats[((int64_t)n * 32 + c / cg) * 2], rstd[e] = stats[((int64_t)n * 32 + c / cg) * 2 + 1];
         }
       }
-      for (int p = p0 + psub; p < p1; p += lanes_p) {
-        const int64_t idx = ((int64_t)n * P + p) * C + 4 * c4;
-        const float4 xv = *reinterpret_cast<const float4*>(x + idx);
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-        if (MODE == 0) {
+      // pixels in batches of 4 so that four (MODE 1: eight) independent 16-byte loads are in flight per thread
+      for (int pb = p0 + psub; pb < p1; pb += 4 * lanes_p) {
+        float4 xv[4], gv[4];
+        bool ok[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s0[e] += xs[e];
-            s1[e] += (double)xs[e] * xs[e];
-          }
-        } else {
-          const float4 gv = *reinterpret_cast<const float4*>(dy + idx);
-          const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        for (int u = 0; u < 4; ++u) {
+          const int p = pb + u * lanes_p;
+          ok[u] = p < p1;
+          const int64_t idx = ((int64_t)n * P + (ok[u] ? p : p0)) * C + 4 * c4;
+          xv[u] = *reinterpret_cast<const float4*>(x + idx);
+          if (MODE == 1) gv[u] = *reinterpret_cast<const float4*>(dy + idx);
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float xh = (xs[e] - mean[e]) * rstd[e];
-            const float t = (xh * ga[e] + be[e]) * sc[e] + sh[e];
-            float g = gs[e];
-            if (act) {
-              const float sg = 1.f / (1.f + __expf(-t));
-              g *= sg * (1.f + t * (1.f - sg));
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+          if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s0[e] += xs[e];
+              s1[e] += (double)xs[e] * xs[e];
             }
-            g *= sc[e] * ga[e];
-            s0[e] += g;
-            s1[e] += (double)g * xh;
+          } else {
+            const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xh = (xs[e] - mean[e]) * rstd[e];
+              const float t = (xh * ga[e] + be[e]) * sc[e] + sh[e];
+              float g = gs[e];
+              if (act) {
+                const float sg = 1.f / (1.f + __expf(-t));
+                g *= sg * (1.f + t * (1.f - sg));
+              }
+              g *= sc[e] * ga[e];
+              s0[e] += g;
+              s1[e] += (double)g * xh;
+            }
           }
         }
       }
@@ -317,11 +335,17 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
 
 // MODE 0 -> (mean, rstd);  MODE 1 -> (mean g, mean g*xhat)
 template <int MODE>
-__global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ partial, float* __restrict__ out,
-                                                    int nchunks, double count) {
-  const int n = blockIdx.x, grp = threadIdx.x >> 1, which = threadIdx.x & 1;
+__global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ partial, float* __restrict__ out,
+                                                     int nchunks, double count) {
+  __shared__ double red[4][64];
+  const int n = blockIdx.x, slot = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
   double s = 0.0;
-  for (int c = 0; c < nchunks; ++c) s += partial[((int64_t)n * nchunks + c) * 64 + threadIdx.x];
+  for (int c = lane4; c < nchunks; c += 4) s += partial[((int64_t)n * nchunks + c) * 64 + slot];
+  red[lane4][slot] = s;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  s = red[0][slot] + red[1][slot] + red[2][slot] + red[3][slot];
+  const int grp = slot >> 1, which = slot & 1;
   const double other = __shfl_xor(s, 1, 64);
   if (MODE == 1) {
     out[((int64_t)n * 32 + grp) * 2 + which] = (float)(s / count);
@@ -336,69 +360,86 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ p
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats,
-                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                  int ss_stride, float* __restrict__ y, int64_t total, int P, int C,
-                                                  int act) {
-  const int cg = C / 32;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
-    const int c = (int)(i % C);
-    const int n = (int)(i / ((int64_t)P * C));
-    const float4 xv = *reinterpret_cast<const float4*>(x + i);
-    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+// Streaming passes.  Workgroup = (image n, chunk of kGnChunk pixels); a thread owns one float4 of channels for its
+// whole pixel loop, so everything that depends on (n, channel) only - mean, rstd, gamma, beta, scale, shift, the
+// backward sums - is folded into per-thread constants once and the loop is load / 4 FMAs (+ SiLU) / store.
+//   forward :  y  = act(x * A + Bc),   A = rstd*gamma*(1+scale),  Bc = (beta - mean*rstd*gamma)*(1+scale) + shift
+//   backward:  dx (+)= rstd * (g - a - xhat * b),  g = dy * act'(t) * (1+scale) * gamma,  (a, b) = sums
+template <int BWD>
+__global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ stats, const float* __restrict__ sums,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   int ss_stride, float* __restrict__ out, int P, int C, int act,
+                                                   int accumulate, int nchunks, int kGnChunk) {
+  const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+  const int cg = C / 32, c4n = C / 4;
+  const int p0 = chunk * kGnChunk;
+  const int p1 = p0 + kGnChunk < P ? p0 + kGnChunk : P;
+  const int lanes_p = c4n >= 256 ? 1 : 256 / c4n;
+  const int active = c4n >= 256 ? 256 : lanes_p * c4n;
+  if ((int)threadIdx.x >= active) return;
+  for (int c4 = threadIdx.x % (c4n < 256 ? c4n : 256); c4 < c4n; c4 += 256) {
+    const int psub = c4n >= 256 ? 0 : threadIdx.x / c4n;
+    float A[4], Bc[4], mean[4], rstd[4], gsc[4], sa[4], sb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int ce = c + e;
-      const float* st = stats + ((int64_t)n * 32 + ce / cg) * 2;
-      float t = (v[e] - st[0]) * st[1] * gamma[ce] + beta[ce];
-      if (scale != nullptr) t = t * (1.f + scale[(int64_t)n * ss_stride + ce]) + shift[(int64_t)n * ss_stride + ce];
-      v[e] = act ? silu_f(t) : t;
+      const int c = 4 * c4 + e;
+      const int64_t si = ((int64_t)n * 32 + c / cg) * 2;
+      mean[e] = stats[si], rstd[e] = stats[si + 1];
+      const float sc = scale != nullptr ? 1.f + scale[(int64_t)n * ss_stride + c] : 1.f;
+      const float sh = shift != nullptr ? shift[(int64_t)n * ss_stride + c] : 0.f;
+      const float rg = rstd[e] * gamma[c];
+      A[e] = rg * sc;
+      Bc[e] = (beta[c] - mean[e] * rg) * sc + sh;
+      gsc[e] = sc * gamma[c];
+      if (BWD) sa[e] = sums[si], sb[e] = sums[si + 1];
     }
-    *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
-  }
-}
-
-// backward pass 2: dx = rstd * (g - mean(g) - xhat * mean(g * xhat))  (+ dx_add when accumulate)
-__global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy,
-                                                      const float* __restrict__ stats, const float* __restrict__ sums,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      int ss_stride, float* __restrict__ dx, int64_t total, int P,
-                                                      int C, int act, int accumulate) {
-  const int cg = C / 32;
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * 1024) {
-    const int c = (int)(i % C);
-    const int n = (int)(i / ((int64_t)P * C));
-    const float4 xv = *reinterpret_cast<const float4*>(x + i);
-    const float4 gv = *reinterpret_cast<const float4*>(dy + i);
-    float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w}, o[4];
-    if (accumulate) {
-      const float4 ov = *reinterpret_cast<const float4*>(dx + i);
-      o[0] = ov.x, o[1] = ov.y, o[2] = ov.z, o[3] = ov.w;
-    } else {
-      o[0] = o[1] = o[2] = o[3] = 0.f;
-    }
+    for (int pb = p0 + psub; pb < p1; pb += 4 * lanes_p) {
+      float4 xv[4], gv[4], ov[4];
+      bool ok[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ce = c + e;
-      const int64_t sidx = ((int64_t)n * 32 + ce / cg) * 2;
-      const float mean = stats[sidx], rstd = stats[sidx + 1];
-      const float xh = (xs[e] - mean) * rstd;
-      float gsc = 1.f, t = xh * gamma[ce] + beta[ce];
-      if (scale != nullptr) {
-        gsc = 1.f + scale[(int64_t)n * ss_stride + ce];
-        t = t * gsc + shift[(int64_t)n * ss_stride + ce];
+      for (int u = 0; u < 4; ++u) {
+        const int p = pb + u * lanes_p;
+        ok[u] = p < p1;
+        const int64_t idx = ((int64_t)n * P + (ok[u] ? p : p0)) * C + 4 * c4;
+        xv[u] = *reinterpret_cast<const float4*>(x + idx);
+        if (BWD) {
+          gv[u] = *reinterpret_cast<const float4*>(dy + idx);
+          if (accumulate) ov[u] = *reinterpret_cast<const float4*>(out + idx);
+        }
       }
-      float g = gs[e];
-      if (act) {
-        const float sg = 1.f / (1.f + __expf(-t));
-        g *= sg * (1.f + t * (1.f - sg));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const int64_t idx = ((int64_t)n * P + pb + u * lanes_p) * C + 4 * c4;
+        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        float o[4];
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = fmaf(xs[e], A[e], Bc[e]);
+            o[e] = act ? silu_f(t) : t;
+          }
+        } else {
+          const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+          const float os[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = fmaf(xs[e], A[e], Bc[e]);
+            const float xh = (xs[e] - mean[e]) * rstd[e];
+            float g = gs[e];
+            if (act) {
+              const float sg = 1.f / (1.f + __expf(-t));
+              g *= sg * (1.f + t * (1.f - sg));
+            }
+            g *= gsc[e];
+            o[e] = (accumulate ? os[e] : 0.f) + rstd[e] * (g - sa[e] - xh * sb[e]);
+          }
+        }
+        *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
       }
-      g *= gsc * gamma[ce];
-      o[e] += rstd * (g - sums[sidx] - xh * sums[sidx + 1]);
     }
-    *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -561,17 +602,21 @@ int fh_bgemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
   return 0;
 }
 
-int64_t fh_groupnorm_scratch_doubles(int N, int P) { return (int64_t)N * ((P + kGnChunk - 1) / kGnChunk) * 64; }
+int64_t fh_groupnorm_scratch_doubles(int N, int P) {
+  const int chunk = gn_chunk(N, P);
+  return (int64_t)N * ((P + chunk - 1) / chunk) * 64;
+}
 
 int fh_groupnorm_stats(const float* x, float* stats, double* scratch, int N, int P, int C, void* stream) {
   if (!x || !stats || !scratch || C % 32 != 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const int kGnChunk = gn_chunk(N, P);
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
   double* part = scratch;
   hipLaunchKernelGGL(k_gn_partial<0>, dim3(N * nchunks), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, 0, part, P, C, 0, nchunks);
-  hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(64), 0, st, (const double*)part, stats, nchunks,
+                     (const float*)nullptr, 0, part, P, C, 0, nchunks, kGnChunk);
+  hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(256), 0, st, (const double*)part, stats, nchunks,
                      (double)P * (C / 32));
   FH_LAUNCH_CHECK();
   return 0;
@@ -580,9 +625,11 @@ int fh_groupnorm_stats(const float* x, float* stats, double* scratch, int N, int
 int fh_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, const float* scale,
                        const float* shift, int ss_stride, float* y, int N, int P, int C, int act, void* stream) {
   if (!x || !stats || !gamma || !beta || !y || C % 32 != 0) return FH_EINVAL;
-  const int64_t total = (int64_t)N * P * C;
-  hipLaunchKernelGGL(k_gn_apply, dim3(grid_for(total, 1024)), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta,
-                     scale, shift, ss_stride, y, total, P, C, act);
+  const int kGnChunk = gn_chunk(N, P);
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  hipLaunchKernelGGL(k_gn_stream<0>, dim3(N * nchunks), dim3(256), 0, (hipStream_t)stream, x, (const float*)nullptr,
+                     stats, (const float*)nullptr, gamma, beta, scale, shift, ss_stride, y, P, C, act, 0, nchunks,
+                     kGnChunk);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -592,15 +639,15 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
                      int P, int C, int act, int accumulate, void* stream) {
   if (!x || !dy || !stats || !gamma || !beta || !sums || !scratch || !dx || C % 32 != 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t total = (int64_t)N * P * C;
+  const int kGnChunk = gn_chunk(N, P);
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
   double* part = scratch;
   hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
-                     ss_stride, part, P, C, act, nchunks);
-  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(64), 0, st, (const double*)part, sums, nchunks,
+                     ss_stride, part, P, C, act, nchunks, kGnChunk);
+  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, st, (const double*)part, sums, nchunks,
                      (double)P * (C / 32));
-  hipLaunchKernelGGL(k_gn_bwd_apply, dim3(grid_for(total, 1024)), dim3(256), 0, st, x, dy, stats, (const float*)sums,
-                     gamma, beta, scale, shift, ss_stride, dx, total, P, C, act, accumulate);
+  hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, (const float*)sums, gamma, beta,
+                     scale, shift, ss_stride, dx, P, C, act, accumulate, nchunks, kGnChunk);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -414,3 +414,15 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             assert rel < 1e-4, r
             tight += 1
     assert tight >= len(rows) // 3
+
+
+def test_dct_variance_prior_matches_scipy(dev):
+    """Row f1 of SURVEY section 8: the producer of dct_variance.pt on the HIP DCT, against SciPy on the host."""
+    import scipy.fft
+    from free_hunch_amd.frequency_analysis import dct_variance
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.randint(0, 256, (20, 3, 64, 64), generator=g, dtype=torch.uint8)
+    got = dct_variance(imgs, device=dev, batch=8).cpu().numpy()
+    x = imgs.numpy().astype(np.float64) / 127.5 - 1
+    ref = (scipy.fft.dctn(x, type=2, norm="ortho", axes=(-2, -1)) ** 2).mean(0)
+    assert np.abs(got - ref).max() < 1e-5 * ref.max()
