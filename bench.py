@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--groups", type=int, default=2, help="lock-step groups per GPU (FH phase of one overlaps UNet of another)")
+    ap.add_argument("--groups", type=int, default=1, help="lock-step groups per GPU (FH phase of one overlaps UNet of another)")
     ap.add_argument("--arch", default="ffhq", choices=["ffhq", "imagenet"])
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--num-steps", type=int, default=30)
