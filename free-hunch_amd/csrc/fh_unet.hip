@@ -30,6 +30,8 @@ struct ConvArgs {
   const float* res;   // [N][Ho][Wo][Cout] or null
   float* out;         // [N][Ho][Wo][Cout]
   int N, H, W, Cin, Cout, KH, KW, pad, stride, Ho, Wo;
+  int ksplit;   // > 1: blockIdx.z owns a contiguous range of K chunks and writes raw partial sums to ws[z][M][Cout]
+  float* ws;
 };
 
 template <int MI, int NI>
@@ -48,7 +50,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int n0 = blockIdx.y * BN;
   const int taps = a.KH * a.KW;
   const int cpt = a.Cin / kBK;  // chunks per tap
-  const int nchunks = taps * cpt;
+  const int nchunks_all = taps * cpt;
+  const int c_begin = (int)((int64_t)nchunks_all * blockIdx.z / a.ksplit);
+  const int c_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / a.ksplit);
 
   // staging coordinates (fixed over the K loop)
   const int ra = tid / TPR_A, ca = (tid % TPR_A) * FA;
@@ -97,12 +101,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(0);
+  load_chunk(c_begin);
   store_chunk(0);
   __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunks) load_chunk(c + 1);
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) load_chunk(c + 1);
 #pragma unroll
     for (int g = 0; g < kBK / 8; ++g) {
       float4 af[MI], bf[NI];
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         }
       }
     }
-    if (c + 1 < nchunks) store_chunk(buf ^ 1);
+    if (c + 1 < c_end) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn + j * 32 + lr;
     if (co >= a.Cout) continue;
-    const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+    const float bv = (a.bias != nullptr && a.ksplit == 1) ? a.bias[co] : 0.f;
+    float* dst = a.ksplit == 1 ? a.out : a.ws + (int64_t)blockIdx.z * M * a.Cout;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -140,11 +145,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < M) {
           float v = acc[i][j][r] + bv;
-          if (a.res != nullptr) v += a.res[row * a.Cout + co];
-          a.out[row * a.Cout + co] = v;
+          if (a.res != nullptr && a.ksplit == 1) v += a.res[row * a.Cout + co];
+          dst[row * a.Cout + co] = v;
         }
       }
     }
+  }
+}
+
+// split-K epilogue: out = sum_z ws[z] + bias (+ res), fixed summation order
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, float* __restrict__ out,
+                                                       int64_t total, int Cout, int ksplit) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    float v = bias != nullptr ? bias[i % Cout] : 0.f;
+    for (int z = 0; z < ksplit; ++z) v += ws[(int64_t)z * total + i];
+    if (res != nullptr) v += res[i];
+    out[i] = v;
   }
 }
 
@@ -561,25 +578,44 @@ inline unsigned grid_for(int64_t work_items, int per_block = 256, int cap = 4096
 // ================================================================================================
 extern "C" {
 
-int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int N, int H,
-                   int W, int Cin, int Cout, int KH, int KW, int pad, int stride, void* stream) {
+int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+  // K-split factor for layers whose output grid cannot fill the chip (8x8 ... 32x32 at small batch)
+  const int64_t M = (int64_t)N * Ho * Wo;
+  const int64_t blocks = ((M + 63) / 64) * ((Cout + 63) / 64);
+  const int nchunks = KH * KW * (Cin / kBK);
+  int z = 1;
+  while (blocks * z < 192 && z < 8 && nchunks / (2 * z) >= 6) z *= 2;
+  return z;
+}
+
+int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, float* ws,
+                   int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                   void* stream) {
   if (!in || !w || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
     return FH_EINVAL;
+  if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
   ConvArgs a;
   a.in = in, a.w = w, a.bias = bias, a.res = res, a.out = out;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
   a.Ho = (H + 2 * pad - KH) / stride + 1;
   a.Wo = (W + 2 * pad - KW) / stride + 1;
+  a.ksplit = ksplit, a.ws = ws;
   const int64_t M = (int64_t)N * a.Ho * a.Wo;
   hipStream_t st = (hipStream_t)stream;
-  // tile choice: 128x128 when it still yields >= 2 workgroups per CU, else shrink M, then N
+  const unsigned Z = (unsigned)ksplit;
+  // tile choice: 128x128 when it still yields >= 1.5 workgroups per CU, else shrink M, then N
   const int64_t b128 = ((M + 127) / 128) * ((Cout + 127) / 128);
-  if (Cout > 64 && b128 >= 384) {
-    hipLaunchKernelGGL((k_conv_igemm<2, 2>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128), dim3(256), 0, st, a);
-  } else if (Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
-    hipLaunchKernelGGL((k_conv_igemm<1, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128), dim3(256), 0, st, a);
+  if (ksplit == 1 && Cout > 64 && b128 >= 384) {
+    hipLaunchKernelGGL((k_conv_igemm<2, 2>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+  } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
+    hipLaunchKernelGGL((k_conv_igemm<1, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((k_conv_igemm<1, 1>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv_igemm<1, 1>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+  }
+  if (ksplit > 1) {
+    const int64_t total = M * Cout;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, bias, res, out, total,
+                       Cout, ksplit);
   }
   FH_LAUNCH_CHECK();
   return 0;

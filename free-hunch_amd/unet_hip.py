@@ -62,8 +62,11 @@ class HipOps:
         pad = c.kh // 2
         out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
         b = c.b if bias_override is None else bias_override
+        ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
+        ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
-                                           None if res is None else res.data_ptr(), out.data_ptr(), N, H, W, Ci, c.co,
+                                           None if res is None else res.data_ptr(), out.data_ptr(),
+                                           None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co,
                                            c.kh, c.kw, pad, 1, _lib.stream()), "fh_conv2d_nhwc")
         return out
 
@@ -75,8 +78,11 @@ class HipOps:
             gp[..., :Co] = g
             g = gp
         out = torch.empty(N, H, W, c.ci, dtype=torch.float32, device=g.device)
+        ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
+        ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None
         _lib.check(self.lib.fh_conv2d_nhwc(g.data_ptr(), c.wd.data_ptr(), None,
-                                           None if res is None else res.data_ptr(), out.data_ptr(), N, H, W, c.co_p,
+                                           None if res is None else res.data_ptr(), out.data_ptr(),
+                                           None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p,
                                            c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_nhwc(dgrad)")
         return out
 

@@ -144,8 +144,12 @@ int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x
 /* Implicit-GEMM convolution on the fp32 matrix cores.  w is [Cout][KH*KW][Cin] (Cin innermost, Cin % 32 == 0);
  * out = conv(in, w) + bias (+ res), out/res are [N][Ho][Wo][Cout].  The input gradient of a stride-1 convolution is
  * the same call with the spatially flipped, in/out-transposed weight copy. */
-int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int N, int H,
-                   int W, int Cin, int Cout, int KH, int KW, int pad, int stride, void* stream);
+int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, float* ws,
+                   int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                   void* stream);
+/* recommended K-split for a layer (1 = none).  With ksplit > 1 the K range is divided over blockIdx.z, raw partial
+ * sums go to ws [ksplit][N*Ho*Wo][Cout] (caller-owned) and a second kernel adds them in a fixed order (+ bias, res). */
+int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 
 /* C[b] = alpha * opA(A[b]) * opB(B[b]), C [M][N] (ldc).  transA = 0: A is [M][K] (lda), 1: [K][M];
  * transB = 0: B is [N][K] (ldb), 1: [K][N].  Batch b in [0, batch): offsets (b / inner) * s?0 + (b % inner) * s?1. */

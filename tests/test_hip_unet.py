@@ -44,8 +44,10 @@ def test_conv_forward_vs_torch(dev, shape):
     wn = w.permute(0, 2, 3, 1).reshape(Co, k * k, Ci).contiguous()
     rn = res.permute(0, 2, 3, 1).contiguous()
     out = torch.empty(N, H, W, Co, device=dev)
-    L.check(lib.fh_conv2d_nhwc(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), N, H, W, Ci, Co,
-                               k, k, k // 2, 1, L.stream()), "conv")
+    ks = lib.fh_conv2d_splitk(N, H, W, Ci, Co, k, k)
+    ws = torch.empty(max(ks, 1), N * H * W, Co, device=dev)
+    L.check(lib.fh_conv2d_nhwc(xn.data_ptr(), wn.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), ws.data_ptr(), ks, N,
+                               H, W, Ci, Co, k, k, k // 2, 1, L.stream()), "conv")
     # exact-fp32 MFMA accumulation: error ~ 1e-7 * sum|a b|
     assert rel(out.permute(0, 3, 1, 2), ref) < 5e-6
 
