@@ -22,6 +22,14 @@ class FhProblem(C.Structure):
                 ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("tap2_dy", c_dp), ("tap2_dx", c_dp), ("tap2_w", c_dp)]
 
 
+FH_MAX_BATCH = 16
+
+
+class FhBatch(C.Structure):
+    _fields_ = [("nimg", C.c_int32), ("pad", C.c_int32), ("D", c_dp * FH_MAX_BATCH), ("r", c_dp * FH_MAX_BATCH),
+                ("B", c_dp * FH_MAX_BATCH), ("M", c_dp * FH_MAX_BATCH), ("mask", c_dp * FH_MAX_BATCH)]
+
+
 class FhCgInfo(C.Structure):
     _fields_ = [("niter", C.c_int32), ("optimal", C.c_int32), ("residual_norm", C.c_double),
                 ("b_norm", C.c_double)]
@@ -57,6 +65,8 @@ _SIGS = {
     "fh_concat_channels": ([c_dp, c_dp, c_dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_layout_nchw_nhwc": ([c_dp, c_dp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_add_f32": ([c_dp, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
+    "fh_cg_solve_batched": ([C.c_void_p, C.POINTER(FhProblem), C.POINTER(FhBatch), c_dp, c_dp, C.POINTER(C.c_double),
+                             C.c_double, C.c_int, C.POINTER(FhCgInfo), C.c_void_p], C.c_int),
     "fh_cg_solve": ([C.c_void_p, C.POINTER(FhProblem), c_dp, c_dp, C.c_double, C.c_double, C.c_int,
                      C.POINTER(FhCgInfo), C.c_void_p], C.c_int),
 }

@@ -132,6 +132,70 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
     return operator._conv(sol, stride=prob.stride, adjoint=True)
 
 
+def solve_customcuda_batched(operators, ys, x0_means, covariance_models, max_rtol, sigma_t, infos_out=None):
+    """The same solve for B independent images in ONE kernel sequence (`fh_cg_solve_batched`): all images share the
+    operator type / taps / noise level and the number of factor columns (they advance in lock-step), each has its own
+    covariance state, measurement and iteration count.  Returns mat [B,3,S,S] float64."""
+    B = len(operators)
+    op0, cov0 = operators[0], covariance_models[0]
+    name = op0.name
+    if name not in _OP_CODE:
+        raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
+                         "'motion_blur', or 'inpainting'.")
+    dev, S = cov0.device, cov0.S
+    ctx = _lib.Context.get(S, 3 * B, 0, slot=5000 + B)  # scratch sized for the whole batch
+    prob, keep = _problem(op0, cov0, _sigma_y2(op0))
+    per = _lib.FhBatch()
+    per.nimg = B
+    m = cov0.famC.m
+    for b, (op, cov) in enumerate(zip(operators, covariance_models)):
+        assert op.name == name and cov.famC.m == m and cov.C.M_dev.shape[1] == cov0.C.M_dev.shape[1], \
+            "lock-step images must share operator type and factor count"
+        per.D[b], per.r[b], per.B[b], per.M[b] = (cov.C.D.data_ptr(), cov.C.r.data_ptr(), cov.famC.B.data_ptr(),
+                                                  cov.C.M_dev.data_ptr())
+        if name == "inpainting":
+            mk = op.mask.to(device=dev, dtype=F64).contiguous()
+            keep.append(mk)
+            per.mask[b] = mk.data_ptr()
+    y64 = torch.cat([y.detach().to(device=dev, dtype=F64) for y in ys], 0).contiguous()
+    x64 = torch.cat([x.detach().to(device=dev, dtype=F64) for x in x0_means], 0).contiguous()
+    planes = 3 * B
+
+    def conv(v, adjoint):
+        """op0's blur on the whole batch (planes = 3B)"""
+        so = S if (adjoint or prob.stride == 1) else S // prob.stride
+        out = torch.empty(B, 3, so, so, dtype=F64, device=dev)
+        t = op0.taps
+        if t.sep is not None and prob.stride == 1:
+            first, second = t.sep if not adjoint else t.sep[::-1]
+            tmp = torch.empty_like(out)
+            ctx.conv(v, tmp, first, planes, 1, adjoint)
+            ctx.conv(tmp, out, second, planes, 1, adjoint)
+        else:
+            ctx.conv(v, out, t, planes, prob.stride, adjoint)
+        return out
+
+    if name == "inpainting":
+        mask = torch.cat([k.view(1, 3, S, S) for k in keep[-B:]], 0)
+        b_vec = ctx.axpby(1.0, (mask * y64).contiguous(), -1.0, (mask * x64).contiguous(), torch.empty_like(x64))
+    else:
+        ax = conv(x64, False)
+        b_vec = ctx.axpby(1.0, y64, -1.0, ax, ax)
+    sol = torch.empty_like(b_vec)
+    rtol = rtol_func(sigma_t, max_rtol)
+    rtols = (C.c_double * B)(*([rtol] * B))
+    infos = (_lib.FhCgInfo * B)()
+    _lib.check(ctx.lib.fh_cg_solve_batched(ctx.h, C.byref(prob), C.byref(per), b_vec.data_ptr(), sol.data_ptr(), rtols,
+                                           0.0, 5000, infos, _lib.stream()), "fh_cg_solve_batched")
+    for b in range(B):
+        if infos[b].niter == (5000 if name == "inpainting" else 2000):
+            warn("CG not converge.")
+        if infos_out is not None:
+            infos_out.append({"niter": infos[b].niter, "optimal": bool(infos[b].optimal),
+                              "residual_norm": infos[b].residual_norm, "rtol": rtol})
+    return sol if name == "inpainting" else conv(sol, True)
+
+
 def choose_solver(operator_name, operator, y, x0_mean, theta0_var=None, covariance_model=None, method="customcuda",
                   max_rtol=1, ortho_tf=None, sigma_t=None, use_rtol_func=False, info_out=None):
     if operator_name not in _OP_CODE:
@@ -198,6 +262,16 @@ class BFGSOnlineUpdate(ConditioningMechanism):
     # input-VJP (sampler.conditional_sampler_batched): fh_solve = covariance updates + CG solve for one image,
     # fh_finish = the 0.2-std branch and the history append.
     def fh_solve(self, x_det, m_det, y, sigma, model=None):
+        self.fh_update(x_det, m_det, sigma, model)
+        info = []
+        mat = choose_solver(self.forward_operator.name, self.forward_operator, y, m_det,
+                            covariance_model=self.covariance_model, method=self.solver_type, max_rtol=self.max_rtol,
+                            sigma_t=float(sigma), info_out=info)
+        self._rec = dict(info[0])
+        return mat
+
+    def fh_update(self, x_det, m_det, sigma, model=None):
+        """the covariance part of a guidance call: time update (sigma changed) and space update (x changed)"""
         cm = self.covariance_model
         s = float(sigma)
         if self.do_space_updates:
@@ -216,11 +290,6 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         elif len(self.sigmas) != 0 and s != self.sigmas[-1]:
             score_previous = (self.denoiser_means[-1] - self.xs[-1]) / self.sigmas[-1] ** 2
             cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous, only_covariance=True)
-        info = []
-        mat = choose_solver(self.forward_operator.name, self.forward_operator, y, m_det, covariance_model=cm,
-                            method=self.solver_type, max_rtol=self.max_rtol, sigma_t=s, info_out=info)
-        self._rec = dict(info[0])
-        return mat
 
     def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma):
         cm, rec, s = self.covariance_model, self._rec, float(sigma)

@@ -46,6 +46,7 @@ struct fh_cg_state {  // device-resident control block of the CG loop
 
 struct fh_graph_entry {  // one instantiated chunk-of-iterations graph, keyed by the problem it was captured for
   fh_problem key;
+  fh_batch bkey;
   int64_t n;
   hipGraphExec_t exec;
   hipGraph_t graph;
@@ -54,6 +55,7 @@ struct fh_graph_entry {  // one instantiated chunk-of-iterations graph, keyed by
 
 struct fh_context {
   int S, planes_max, m_cap;
+  int nimg_max;       // images a batched call may carry = max(1, planes_max / 3)
   double* basis;      // [S][S]  C[k][n] = s_k cos(pi (2n+1) k / 2S)
   double* basis_t;    // [S][S]  transpose
   double* tmp_img;    // [planes_max*S*S] DCT intermediate

@@ -16,8 +16,14 @@
 
 using namespace fh;
 
-#define DONE_GUARD(done) \
-  if ((done) != nullptr && *(done) != 0) return
+// Kernels inside the CG loop are gated per image: `states` is the array of device-resident CG control blocks (null
+// outside the loop) and a workgroup returns at once when its image has met its stopping rule.
+#define IMG_GUARD(states, img) \
+  if ((states) != nullptr && (states)[(img)].done != 0) return
+
+struct RtolArr {
+  double v[FH_MAX_BATCH];
+};
 
 // ------------------------------------------------------------------------------------------------
 // float64 GEMM for the two DCT passes on the matrix cores (v_mfma_f64_16x16x4_f64):
@@ -32,8 +38,8 @@ template <bool BT>
 __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                   int ldc, int64_t sA, int64_t sB, int64_t sC,
-                                                  const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                                  const fh_cg_state* __restrict__ states, int rows_per_plane) {
+  IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * 32) / rows_per_plane) / 3);
   constexpr int BM = 32, BN = 32, BK = 32, LD = BK + 2;
   __shared__ double As[2][BM][LD];
   __shared__ double Bs[2][BN][LD];
@@ -107,8 +113,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   }
 }
 
-static int dct2d_launch(fh_context* ctx, const double* in, double* out, int planes, int inverse, const int* done,
-                        hipStream_t st) {
+static int dct2d_launch(fh_context* ctx, const double* in, double* out, int planes, int inverse,
+                        const fh_cg_state* states, hipStream_t st) {
   const int S = ctx->S;
   if (planes > ctx->planes_max) return FH_ESIZE;
   const double* b1 = inverse ? ctx->basis_t : ctx->basis;
@@ -116,13 +122,13 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
   {
     dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
     hipLaunchKernelGGL(k_gemm_f64<true>, grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                       (int64_t)0, (int64_t)0, (int64_t)0, done);
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
   }
   // pass 2 (along H), per plane: Y[k][w] = sum_n b1[k][n] * T[n][w]
   {
     dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
     hipLaunchKernelGGL(k_gemm_f64<false>, grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, done);
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
   }
   FH_LAUNCH_CHECK();
   return 0;
@@ -145,10 +151,15 @@ constexpr int kColChunk = 8;    // columns held in registers per wave and sweep
 // base at m = 32 (a pure streaming read of the same bytes reaches 5.6 TB/s).  Each wave writes its sums as block
 // partials; k_rep_coef (one 1024-thread workgroup) adds them in a fixed order and forms c = M t.  (float64 atomics
 // into a shared m-vector were measured 2x SLOWER than this: 8192 same-address adds serialise at the memory side.)
-__global__ __launch_bounds__(256) void k_rep_dots(const double* __restrict__ B, const double* __restrict__ r,
-                                                  const double* __restrict__ z, double* __restrict__ partial,
-                                                  int64_t d, int m, const int* __restrict__ done) {
-  DONE_GUARD(done);
+__global__ __launch_bounds__(256) void k_rep_dots(fh_batch per, const double* __restrict__ z,
+                                                  double* __restrict__ partial, int64_t d, int m,
+                                                  const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  const double* __restrict__ B = per.B[img];
+  const double* __restrict__ r = per.r[img];
+  z += (int64_t)img * d;
+  partial += (int64_t)img * kPartialRows * FH_MAX_COLS;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * kDotRows;
   constexpr int kIter = kDotRows / 128;  // row pairs per lane
@@ -189,10 +200,14 @@ __global__ __launch_bounds__(256) void k_rep_dots(const double* __restrict__ B, 
 
 // pass 1b: t[j] = sum_b partial[b][j] (fixed order -> deterministic), c = M t.  One workgroup of 1024 threads:
 // 32 row-groups x 32 columns keep nparts/32 coalesced loads per thread in flight.
-__global__ __launch_bounds__(1024) void k_rep_coef(const double* __restrict__ partial, int nparts,
-                                                   const double* __restrict__ M, int ldm, int m,
-                                                   double* __restrict__ coef, const int* __restrict__ done) {
-  DONE_GUARD(done);
+__global__ __launch_bounds__(1024) void k_rep_coef(fh_batch per, const double* __restrict__ partial, int nparts,
+                                                   int ldm, int m, double* __restrict__ coef,
+                                                   const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  const double* __restrict__ M = per.M[img];
+  partial += (int64_t)img * kPartialRows * FH_MAX_COLS;
+  coef += (int64_t)img * 2 * FH_MAX_COLS;
   __shared__ double t[FH_MAX_COLS];
   __shared__ double red[32][33];
   const int tid = threadIdx.x, jj = tid & 31, rg = tid >> 5;
@@ -233,11 +248,17 @@ __global__ __launch_bounds__(1024) void k_rep_coef(const double* __restrict__ pa
 }
 
 // pass 2: out = D.*z + r.*(B c), rows swept in the opposite order of pass 1 (Infinity-Cache reuse).
-__global__ __launch_bounds__(256) void k_rep_apply2(const double* __restrict__ D, const double* __restrict__ r,
-                                                    const double* __restrict__ B, const double* __restrict__ coef,
+__global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* __restrict__ coef,
                                                     const double* __restrict__ z, double* __restrict__ out,
-                                                    int64_t d, int m, const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                                    int64_t d, int m, const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  const double* __restrict__ D = per.D[img];
+  const double* __restrict__ r = per.r[img];
+  const double* __restrict__ B = per.B[img];
+  coef += (int64_t)img * 2 * FH_MAX_COLS;
+  z += (int64_t)img * d;
+  out += (int64_t)img * d;
   const int tid = threadIdx.x;
   __shared__ double c[FH_MAX_COLS];
   for (int j = tid; j < m; j += 256) c[j] = coef[j];
@@ -264,18 +285,18 @@ __global__ __launch_bounds__(256) void k_rep_apply2(const double* __restrict__ D
   }
 }
 
-static int rep_apply_launch(fh_context* ctx, const double* D, const double* r, const double* B, const double* M,
-                            int ldm, const double* z, double* out, int64_t d, int m, const int* done,
-                            hipStream_t st) {
-  if (m < 0 || m > FH_MAX_COLS || (d & 1)) return FH_ESIZE;
+static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const double* z, double* out, int64_t d,
+                            int m, const fh_cg_state* states, hipStream_t st) {
+  if (m < 0 || m > FH_MAX_COLS || (d & 1) || per.nimg < 1 || per.nimg > ctx->nimg_max) return FH_ESIZE;
   const int nb = (int)((d + kDotRows - 1) / kDotRows);
   if (nb > kPartialRows) return FH_ESIZE;
+  const unsigned Z = (unsigned)per.nimg;
   if (m > 0) {
-    hipLaunchKernelGGL(k_rep_dots, dim3(nb), dim3(256), 0, st, B, r, z, ctx->partial, d, m, done);
-    hipLaunchKernelGGL(k_rep_coef, dim3(1), dim3(1024), 0, st, (const double*)ctx->partial, nb, M, ldm, m, ctx->coef,
-                       done);
+    hipLaunchKernelGGL(k_rep_dots, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
+    hipLaunchKernelGGL(k_rep_coef, dim3(1, 1, Z), dim3(1024), 0, st, per, (const double*)ctx->partial, nb, ldm, m,
+                       ctx->coef, states);
   }
-  hipLaunchKernelGGL(k_rep_apply2, dim3(nb), dim3(256), 0, st, D, r, B, (const double*)ctx->coef, z, out, d, m, done);
+  hipLaunchKernelGGL(k_rep_apply2, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m, states);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -399,9 +420,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
 // Elementwise helpers and scalar reductions
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_axpby(double alpha, const double* __restrict__ a, double beta,
-                                               const double* __restrict__ b, double* __restrict__ out, int64_t n,
-                                               const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                               const double* __restrict__ b, double* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double v = alpha * a[i];
     if (b != nullptr) v = fma(beta, b[i], v);
@@ -409,11 +428,17 @@ __global__ __launch_bounds__(256) void k_axpby(double alpha, const double* __res
   }
 }
 
-// out = mask .* in  (add == null)   |   out = add_scale*add + mask .* in
-__global__ __launch_bounds__(256) void k_mask(const double* __restrict__ mask, const double* __restrict__ in,
+// out = mask .* in  (add == null)   |   out = add_scale*add + mask .* in      (grid z = image)
+__global__ __launch_bounds__(256) void k_mask(fh_batch per, const double* __restrict__ in,
                                               const double* __restrict__ add, double add_scale,
-                                              double* __restrict__ out, int64_t n, const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                              double* __restrict__ out, int64_t n,
+                                              const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  const double* __restrict__ mask = per.mask[img];
+  in += (int64_t)img * n;
+  out += (int64_t)img * n;
+  if (add != nullptr) add += (int64_t)img * n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double v = mask[i] * in[i];
     if (add != nullptr) v = fma(add_scale, add[i], v);
@@ -423,12 +448,16 @@ __global__ __launch_bounds__(256) void k_mask(const double* __restrict__ mask, c
 
 constexpr int kDotBlocks = 256;
 
-// partial[b] = sum over block b of a.*b ; optional second product a2.*b2 -> partial[kDotBlocks + b]
+// partial[b] = sum over block b of a.*b ; optional second product a2.*b2 -> partial[kDotBlocks + b]   (grid z = image)
 __global__ __launch_bounds__(256) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
                                                      const double* __restrict__ a2, const double* __restrict__ b2,
-                                                     double* __restrict__ part, int64_t n,
-                                                     const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                                     double* __restrict__ part, int64_t n, int part_stride,
+                                                     const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  a += (int64_t)img * n;
+  b += (int64_t)img * n;
+  part += (int64_t)img * part_stride;
   __shared__ double red[4];
   double s = 0.0, s2 = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -503,8 +532,8 @@ __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in
                                                    const int* __restrict__ tdy, const int* __restrict__ tdx,
                                                    const double* __restrict__ tw, int ntaps, int S, int halo,
                                                    int adjoint, int up, const double* __restrict__ add,
-                                                   double add_scale, const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                                   double add_scale, const fh_cg_state* __restrict__ states) {
+  IMG_GUARD(states, blockIdx.z / 3);
   extern __shared__ __align__(16) double tile[];  // [sh*sw] tile | [ntaps] weights | [ntaps] int offsets
   const int sw = 32 + 2 * halo, sh = 16 + 2 * halo;
   double* s_w = tile + sw * sh;
@@ -572,13 +601,13 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ 
                                                      const int* __restrict__ tdy, const int* __restrict__ tdx,
                                                      const double* __restrict__ tw, int ntaps, int S, int stride,
                                                      int planes, const double* __restrict__ add, double add_scale,
-                                                     const int* __restrict__ done) {
-  DONE_GUARD(done);
+                                                     const fh_cg_state* __restrict__ states) {
   const int So = S / stride;
   const int64_t total = (int64_t)planes * So * So;
   const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= total) return;
   const int plane = (int)(o / ((int64_t)So * So));
+  IMG_GUARD(states, plane / 3);
   const int rem = (int)(o % ((int64_t)So * So));
   const int oy = (rem / So) * stride, ox = (rem % So) * stride;
   const double* src = in + (int64_t)plane * S * S;
@@ -595,7 +624,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ 
 
 static int conv_launch(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
                        const double* w, int ntaps, int halo, int planes, int stride, int adjoint, const double* add,
-                       double add_scale, const int* done, hipStream_t st) {
+                       double add_scale, const fh_cg_state* done, hipStream_t st) {
   const int S = ctx->S;
   if (stride < 1 || S % stride != 0 || halo < 0 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
   if (!adjoint && stride > 1) {
@@ -617,61 +646,69 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
 // ------------------------------------------------------------------------------------------------
 // A_mm(u) = sigma_y^2 u + A C A^T u       (conditioning_mechanisms.py:395-400, 505-511, 653-659)
 // ------------------------------------------------------------------------------------------------
-static int amm_launch(fh_context* ctx, const fh_problem* p, const double* u, double* out, const int* done,
-                      hipStream_t st) {
+static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per, const double* u, double* out,
+                      const fh_cg_state* states, hipStream_t st) {
   const int S = ctx->S;
-  const int64_t d = p->d;
-  if (d != (int64_t)p->planes * S * S) return FH_EINVAL;
+  const int64_t d = p->d;  // per image
+  const int nimg = per.nimg;
+  const int planes = p->planes * nimg;
+  if (d != (int64_t)p->planes * S * S || p->planes != 3 || nimg < 1 || nimg > ctx->nimg_max) return FH_EINVAL;
   int rc;
   double *w0 = ctx->w0, *w1 = ctx->w1;
   const int halo = p->halo;
+  const dim3 egrid(512, 1, (unsigned)nimg);
   const bool sep = p->ntaps2 > 0;  // separable PSF: two 1-D passes (blur only, stride 1)
   if (sep && p->stride != 1) return FH_EINVAL;
   // w0 = A^T u
   if (p->op == 0) {
-    hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, u, (const double*)nullptr, 0.0, w0, d, done);
+    hipLaunchKernelGGL(k_mask, egrid, dim3(256), 0, st, per, u, (const double*)nullptr, 0.0, w0, d, states);
   } else if (sep) {
-    rc = conv_launch(ctx, u, w1, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, p->planes, 1, 1, nullptr, 0.0,
-                     done, st);
+    rc = conv_launch(ctx, u, w1, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, planes, 1, 1, nullptr, 0.0,
+                     states, st);
     if (rc) return rc;
-    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, 1, 1, nullptr, 0.0, done,
-                     st);
+    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, planes, 1, 1, nullptr, 0.0, states, st);
     if (rc) return rc;
   } else {
-    rc = conv_launch(ctx, u, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 1, nullptr,
-                     0.0, done, st);
+    rc = conv_launch(ctx, u, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, planes, p->stride, 1, nullptr, 0.0,
+                     states, st);
     if (rc) return rc;
   }
   // w0 <- C w0  (through the DCT basis when the covariance lives there)
   if (p->use_dct) {
-    rc = dct2d_launch(ctx, w0, w1, p->planes, 0, done, st);
+    rc = dct2d_launch(ctx, w0, w1, planes, 0, states, st);
     if (rc) return rc;
-    rc = rep_apply_launch(ctx, p->D, p->r, p->B, p->M, p->ldm, w1, w0, d, p->m, done, st);
+    rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
     if (rc) return rc;
-    rc = dct2d_launch(ctx, w0, w1, p->planes, 1, done, st);
+    rc = dct2d_launch(ctx, w0, w1, planes, 1, states, st);
     if (rc) return rc;
   } else {
-    rc = rep_apply_launch(ctx, p->D, p->r, p->B, p->M, p->ldm, w0, w1, d, p->m, done, st);
+    rc = rep_apply_launch(ctx, per, p->ldm, w0, w1, d, p->m, states, st);
     if (rc) return rc;
   }
   // out = sigma_y^2 u + A w1
   if (p->op == 0) {
-    hipLaunchKernelGGL(k_mask, dim3(512), dim3(256), 0, st, p->mask, (const double*)w1, u, p->sigma_y2, out, d,
-                       done);
+    hipLaunchKernelGGL(k_mask, egrid, dim3(256), 0, st, per, (const double*)w1, u, p->sigma_y2, out, d, states);
   } else if (sep) {
-    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, 1, 0, nullptr, 0.0, done,
-                     st);
+    rc = conv_launch(ctx, w1, w0, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, planes, 1, 0, nullptr, 0.0, states, st);
     if (rc) return rc;
-    rc = conv_launch(ctx, w0, out, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, p->planes, 1, 0, u,
-                     p->sigma_y2, done, st);
+    rc = conv_launch(ctx, w0, out, p->tap2_dy, p->tap2_dx, p->tap2_w, p->ntaps2, p->halo2, planes, 1, 0, u, p->sigma_y2,
+                     states, st);
     if (rc) return rc;
   } else {
-    rc = conv_launch(ctx, w1, out, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, p->planes, p->stride, 0, u,
-                     p->sigma_y2, done, st);
+    rc = conv_launch(ctx, w1, out, p->tap_dy, p->tap_dx, p->tap_w, p->ntaps, halo, planes, p->stride, 0, u, p->sigma_y2,
+                     states, st);
     if (rc) return rc;
   }
   FH_LAUNCH_CHECK();
   return 0;
+}
+
+static fh_batch batch_of(const fh_problem* p) {
+  fh_batch per;
+  memset(&per, 0, sizeof(per));
+  per.nimg = 1;
+  per.D[0] = p->D, per.r[0] = p->r, per.B[0] = p->B, per.M[0] = p->M, per.mask[0] = p->mask;
+  return per;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,6 +716,7 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const double* u, dou
 // the two reductions per iteration are block partials re-summed by every workgroup of the next kernel.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCgBlocks = 192;
+constexpr int kCgScratch = 4 * kDotBlocks + 16;  // doubles of w2 per image: [pAp | b.b | r.r | - | rzbuf[2]]
 
 __device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* red) {
   double s = threadIdx.x < n ? part[threadIdx.x] : 0.0;
@@ -689,6 +727,11 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
 __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, const double* __restrict__ Ab,
                                                  double* __restrict__ x, double* __restrict__ r,
                                                  double* __restrict__ p, double* __restrict__ part, int64_t n) {
+  {
+    const int64_t off = (int64_t)blockIdx.z * n;
+    b += off, Ab += off, x += off, r += off, p += off;
+    part += (int64_t)blockIdx.z * kCgScratch;
+  }
   __shared__ double red[4];
   double srr = 0.0, sbb = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -707,9 +750,13 @@ __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, c
   }
 }
 
-__global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ part, int nparts, double rtol,
+__global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ part, int nparts, RtolArr rtols,
                                                      double atol, int maxiter, fh_cg_state* __restrict__ stt,
                                                      double* __restrict__ rzbuf) {
+  const double rtol = rtols.v[blockIdx.z];
+  part += (int64_t)blockIdx.z * kCgScratch;
+  rzbuf += (int64_t)blockIdx.z * kCgScratch;
+  stt += blockIdx.z;
   __shared__ double red[4];
   const double srr = sum_partials(part, nparts, red);
   const double sbb = sum_partials(part + kDotBlocks, nparts, red);
@@ -735,6 +782,12 @@ __global__ __launch_bounds__(256) void k_cg_step1(const double* __restrict__ p, 
                                                   const double* __restrict__ part_pap, int nparts,
                                                   double* __restrict__ part_rr, const double* __restrict__ rzbuf,
                                                   fh_cg_state* __restrict__ stt, int64_t n) {
+  {
+    const int64_t off = (int64_t)blockIdx.z * n, so = (int64_t)blockIdx.z * kCgScratch;
+    p += off, ap += off, x += off, r += off;
+    part_pap += so, part_rr += so, rzbuf += so;
+    stt += blockIdx.z;
+  }
   if (stt->done) return;
   const int it = stt->it, k = it + 1;
   if (it >= stt->maxiter) {  // cg.py:245 loop bound; the host reports niter = maxiter
@@ -769,6 +822,12 @@ __global__ __launch_bounds__(256) void k_cg_step2(const double* __restrict__ r, 
                                                   const double* __restrict__ part_rr, int nparts,
                                                   double* __restrict__ rzbuf, fh_cg_state* __restrict__ stt,
                                                   int64_t n) {
+  {
+    const int64_t off = (int64_t)blockIdx.z * n, so = (int64_t)blockIdx.z * kCgScratch;
+    r += off, p += off;
+    part_rr += so, rzbuf += so;
+    stt += blockIdx.z;
+  }
   if (stt->done) return;
   const int k = stt->k_cur;
   __shared__ double red[4];
@@ -808,6 +867,8 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   memset(c, 0, sizeof(*c));
   c->S = S;
   c->planes_max = planes_max;
+  c->nimg_max = planes_max / 3 > 0 ? planes_max / 3 : 1;
+  if (c->nimg_max > FH_MAX_BATCH) c->nimg_max = FH_MAX_BATCH;
   c->m_cap = m_cap;
   const size_t nimg = (size_t)planes_max * S * S;
   std::vector<double> bas((size_t)S * S), bast((size_t)S * S);
@@ -827,9 +888,9 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMemcpy(c->basis, bas.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
   FH_CHECK(hipMemcpy(c->basis_t, bast.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
   FH_CHECK(hipMalloc(&c->tmp_img, sizeof(double) * nimg));
-  FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS));
+  FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS * c->nimg_max));
   FH_CHECK(hipMalloc(&c->gpartial, sizeof(double) * c->gpartial_elems));
-  FH_CHECK(hipMalloc(&c->coef, sizeof(double) * 2 * FH_MAX_COLS));
+  FH_CHECK(hipMalloc(&c->coef, sizeof(double) * 2 * FH_MAX_COLS * c->nimg_max));
   FH_CHECK(hipMemset(c->coef, 0, sizeof(double) * 2 * FH_MAX_COLS));
   FH_CHECK(hipMalloc(&c->cg_r, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->cg_p, sizeof(double) * nimg));
@@ -837,10 +898,10 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->cg_x, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->w0, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->w1, sizeof(double) * nimg));
-  FH_CHECK(hipMalloc(&c->w2, sizeof(double) * (4 * kDotBlocks + 16)));
-  FH_CHECK(hipMalloc(&c->cg_state, sizeof(fh_cg_state)));
-  FH_CHECK(hipMemset(c->cg_state, 0, sizeof(fh_cg_state)));
-  FH_CHECK(hipHostMalloc((void**)&c->h_state, sizeof(fh_cg_state), hipHostMallocDefault));
+  FH_CHECK(hipMalloc(&c->w2, sizeof(double) * kCgScratch * c->nimg_max));
+  FH_CHECK(hipMalloc(&c->cg_state, sizeof(fh_cg_state) * c->nimg_max));
+  FH_CHECK(hipMemset(c->cg_state, 0, sizeof(fh_cg_state) * c->nimg_max));
+  FH_CHECK(hipHostMalloc((void**)&c->h_state, sizeof(fh_cg_state) * c->nimg_max, hipHostMallocDefault));
   FH_CHECK(hipHostMalloc((void**)&c->h_scal, sizeof(double) * 64, hipHostMallocDefault));
   *out = c;
   return 0;
@@ -873,7 +934,11 @@ int fh_rep_apply(fh_context* ctx, const double* D, const double* r, const double
                  const double* z, double* out, int64_t d, int m, void* stream) {
   if (!ctx || !D || !z || !out || d < 2) return FH_EINVAL;
   if (m > 0 && (!r || !B || !M || ldm < m)) return FH_EINVAL;
-  return rep_apply_launch(ctx, D, r, B, M, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
+  fh_batch per;
+  memset(&per, 0, sizeof(per));
+  per.nimg = 1;
+  per.D[0] = D, per.r[0] = r, per.B[0] = B, per.M[0] = M;
+  return rep_apply_launch(ctx, per, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
 }
 
 int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,
@@ -912,7 +977,7 @@ int fh_dot(fh_context* ctx, const double* a, const double* b, double* scal, int 
   if (!ctx || !a || !b || !scal || slot < 0) return FH_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_dot_partial, dim3(kDotBlocks), dim3(256), 0, st, a, b, (const double*)nullptr,
-                     (const double*)nullptr, ctx->w2, d, (const int*)nullptr);
+                     (const double*)nullptr, ctx->w2, d, 0, (const fh_cg_state*)nullptr);
   hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, st, (const double*)ctx->w2, kDotBlocks, scal + slot);
   FH_LAUNCH_CHECK();
   return 0;
@@ -931,8 +996,7 @@ int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double
 
 int fh_axpby(double alpha, const double* a, double beta, const double* b, double* out, int64_t n, void* stream) {
   if (!a || !out || n < 1) return FH_EINVAL;
-  hipLaunchKernelGGL(k_axpby, dim3(512), dim3(256), 0, (hipStream_t)stream, alpha, a, beta, b, out, n,
-                     (const int*)nullptr);
+  hipLaunchKernelGGL(k_axpby, dim3(512), dim3(256), 0, (hipStream_t)stream, alpha, a, beta, b, out, n);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -954,24 +1018,26 @@ int fh_conv_circ(fh_context* ctx, const double* in, double* out, const int32_t* 
 
 int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, void* stream) {
   if (!ctx || !p || !u || !out) return FH_EINVAL;
-  return amm_launch(ctx, p, u, out, nullptr, (hipStream_t)stream);
+  return amm_launch(ctx, p, batch_of(p), u, out, nullptr, (hipStream_t)stream);
 }
 
-// One chunk of CG iterations, enqueued on `st` (eagerly, or while the stream is being captured into a graph).
-static int cg_enqueue_chunk(fh_context* ctx, const fh_problem* p, int64_t n, int count, hipStream_t st) {
+// One chunk of CG iterations for all images of the batch, enqueued on `st` (eagerly, or while the stream is being
+// captured into a graph).
+static int cg_enqueue_chunk(fh_context* ctx, const fh_problem* p, const fh_batch& per, int64_t n, int count,
+                            hipStream_t st) {
   double *x = ctx->cg_x, *r = ctx->cg_r, *pk = ctx->cg_p, *ap = ctx->cg_ap;
   double* part = ctx->w2;
   double* rzbuf = ctx->w2 + 4 * kDotBlocks;
   fh_cg_state* stt = ctx->cg_state;
-  const int* done = &stt->done;
+  const dim3 grid(kCgBlocks, 1, (unsigned)per.nimg);
   for (int i = 0; i < count; ++i) {
-    int rc = amm_launch(ctx, p, pk, ap, done, st);
+    int rc = amm_launch(ctx, p, per, pk, ap, stt, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap,
-                       (const double*)nullptr, (const double*)nullptr, part, n, done);
-    hipLaunchKernelGGL(k_cg_step1, dim3(kCgBlocks), dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
+    hipLaunchKernelGGL(k_dot_partial, grid, dim3(256), 0, st, (const double*)pk, (const double*)ap,
+                       (const double*)nullptr, (const double*)nullptr, part, n, kCgScratch, (const fh_cg_state*)stt);
+    hipLaunchKernelGGL(k_cg_step1, grid, dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
                        (const double*)part, kCgBlocks, part + 2 * kDotBlocks, (const double*)rzbuf, stt, n);
-    hipLaunchKernelGGL(k_cg_step2, dim3(kCgBlocks), dim3(256), 0, st, (const double*)r, pk,
+    hipLaunchKernelGGL(k_cg_step2, grid, dim3(256), 0, st, (const double*)r, pk,
                        (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, n);
   }
   return 0;
@@ -979,13 +1045,15 @@ static int cg_enqueue_chunk(fh_context* ctx, const fh_problem* p, int64_t n, int
 
 // The iteration body depends on device state only (counter, scalars, done flag), so a chunk is captured once per
 // (problem, pointers, m) into a hipGraph and replayed: one host call per 8 iterations instead of ~110 launches.
-static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, int64_t n, int chunk, hipStream_t st) {
+static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, const fh_batch& per, int64_t n, int chunk,
+                                   hipStream_t st) {
   if (ctx->graphs_disabled) return nullptr;
   if (getenv("FH_NO_GRAPH") != nullptr) return nullptr;  // A/B switch for profiling
   ++ctx->graph_clock;
   fh_graph_entry* slot = &ctx->graphs[0];
   for (auto& g : ctx->graphs) {
-    if (g.exec != nullptr && g.n == n && memcmp(&g.key, p, sizeof(fh_problem)) == 0) {
+    if (g.exec != nullptr && g.n == n && memcmp(&g.key, p, sizeof(fh_problem)) == 0 &&
+        memcmp(&g.bkey, &per, sizeof(fh_batch)) == 0) {
       g.stamp = ctx->graph_clock;
       return g.exec;
     }
@@ -1001,8 +1069,7 @@ static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, int64_t
     ctx->graphs_disabled = 1;  // e.g. the legacy null stream: stay on eager launches
     return nullptr;
   }
-  // t_parity etc. are not involved; the enqueue only records launches
-  const int rc = cg_enqueue_chunk(ctx, p, n, chunk, st);
+  const int rc = cg_enqueue_chunk(ctx, p, per, n, chunk, st);
   hipGraph_t graph = nullptr;
   const hipError_t e = hipStreamEndCapture(st, &graph);
   if (rc != 0 || e != hipSuccess || graph == nullptr) {
@@ -1019,6 +1086,7 @@ static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, int64_t
     return nullptr;
   }
   memcpy(&slot->key, p, sizeof(fh_problem));
+  memcpy(&slot->bkey, &per, sizeof(fh_batch));
   slot->n = n;
   slot->exec = exec;
   slot->graph = graph;
@@ -1026,43 +1094,63 @@ static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, int64_t
   return exec;
 }
 
-int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
-                int maxiter, fh_cg_info* info, void* stream) {
-  if (!ctx || !p || !b || !x || !info || maxiter < 1 || !(rtol > 0 || atol > 0)) return FH_EINVAL;
+int fh_cg_solve_batched(fh_context* ctx, const fh_problem* p, const fh_batch* perp, const double* b, double* x,
+                        const double* rtol_host, double atol, int maxiter, fh_cg_info* info, void* stream) {
+  if (!ctx || !p || !perp || !b || !x || !rtol_host || !info || maxiter < 1) return FH_EINVAL;
+  const fh_batch& per = *perp;
+  const int nimg = per.nimg;
+  if (nimg < 1 || nimg > ctx->nimg_max || nimg > FH_MAX_BATCH) return FH_ESIZE;
   hipStream_t st = (hipStream_t)stream;
   const int S = ctx->S;
   const int So = S / (p->op == 2 ? p->stride : 1);
-  const int64_t n = (int64_t)p->planes * So * So;  // measurement dimension
+  const int64_t n = (int64_t)p->planes * So * So;  // measurement dimension per image
   double *r = ctx->cg_r, *pk = ctx->cg_p, *ap = ctx->cg_ap;
-  double* part = ctx->w2;                      // [0,256) pAp / init r.r ; [256,512) init b.b ; [512,768) r.r
-  double* rzbuf = ctx->w2 + 4 * kDotBlocks;    // [2]
+  double* part = ctx->w2;                      // per image: [0,256) pAp / init r.r ; [256,512) init b.b ; [512,768) r.r
+  double* rzbuf = ctx->w2 + 4 * kDotBlocks;    // per image: [2]
   fh_cg_state* stt = ctx->cg_state;
-  int rc = amm_launch(ctx, p, b, ap, nullptr, st);  // A x0 with x0 = b
+  RtolArr rt;
+  for (int i = 0; i < FH_MAX_BATCH; ++i) rt.v[i] = i < nimg ? rtol_host[i] : 1.0;
+  for (int i = 0; i < nimg; ++i)
+    if (!(rtol_host[i] > 0 || atol > 0)) return FH_EINVAL;
+  int rc = amm_launch(ctx, p, per, b, ap, nullptr, st);  // A x0 with x0 = b
   if (rc) return rc;
-  hipLaunchKernelGGL(k_cg_init, dim3(kCgBlocks), dim3(256), 0, st, b, (const double*)ap, ctx->cg_x, r, pk, part, n);
-  hipLaunchKernelGGL(k_cg_init_fin, dim3(1), dim3(256), 0, st, (const double*)part, kCgBlocks, rtol, atol, maxiter,
-                     stt, rzbuf);
+  const dim3 grid(kCgBlocks, 1, (unsigned)nimg);
+  hipLaunchKernelGGL(k_cg_init, grid, dim3(256), 0, st, b, (const double*)ap, ctx->cg_x, r, pk, part, n);
+  hipLaunchKernelGGL(k_cg_init_fin, dim3(1, 1, (unsigned)nimg), dim3(256), 0, st, (const double*)part, kCgBlocks, rt,
+                     atol, maxiter, stt, rzbuf);
   const int chunk = 8;
-  hipGraphExec_t exec = cg_graph_for(ctx, p, n, chunk, st);
-  fh_cg_state& h = *ctx->h_state;  // pinned: the periodic read-back is a true async copy
-  memset(&h, 0, sizeof(h));
-  for (int launched = 0; launched < maxiter + chunk && !h.done; launched += chunk) {
+  hipGraphExec_t exec = cg_graph_for(ctx, p, per, n, chunk, st);
+  fh_cg_state* h = ctx->h_state;  // pinned: the periodic read-back is a true async copy
+  memset(h, 0, sizeof(fh_cg_state) * nimg);
+  bool all_done = false;
+  for (int launched = 0; launched < maxiter + chunk && !all_done; launched += chunk) {
     if (exec != nullptr) {
       FH_CHECK(hipGraphLaunch(exec, st));
     } else {
-      rc = cg_enqueue_chunk(ctx, p, n, chunk, st);
+      rc = cg_enqueue_chunk(ctx, p, per, n, chunk, st);
       if (rc) return rc;
     }
-    FH_CHECK(hipMemcpyAsync(ctx->h_state, stt, sizeof(fh_cg_state), hipMemcpyDeviceToHost, st));
+    FH_CHECK(hipMemcpyAsync(h, stt, sizeof(fh_cg_state) * nimg, hipMemcpyDeviceToHost, st));
     FH_CHECK(hipStreamSynchronize(st));
+    all_done = true;
+    for (int i = 0; i < nimg; ++i) all_done = all_done && h[i].done != 0;
   }
-  FH_CHECK(hipMemcpyAsync(x, ctx->cg_x, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  FH_CHECK(hipMemcpyAsync(x, ctx->cg_x, sizeof(double) * n * nimg, hipMemcpyDeviceToDevice, st));
   FH_LAUNCH_CHECK();
-  info->niter = (h.done == 1 || h.done == 2) ? h.niter : maxiter;
-  info->optimal = h.optimal;
-  info->residual_norm = h.rnorm;
-  info->b_norm = h.bnorm;
+  for (int i = 0; i < nimg; ++i) {
+    info[i].niter = (h[i].done == 1 || h[i].done == 2) ? h[i].niter : maxiter;
+    info[i].optimal = h[i].optimal;
+    info[i].residual_norm = h[i].rnorm;
+    info[i].b_norm = h[i].bnorm;
+  }
   return 0;
+}
+
+int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
+                int maxiter, fh_cg_info* info, void* stream) {
+  if (!p) return FH_EINVAL;
+  const fh_batch per = batch_of(p);
+  return fh_cg_solve_batched(ctx, p, &per, b, x, &rtol, atol, maxiter, info, stream);
 }
 
 }  // extern "C"

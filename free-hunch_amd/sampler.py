@@ -5,7 +5,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .conditioning_mechanisms import choose_conditioning_mechanism
+from .conditioning_mechanisms import choose_conditioning_mechanism, solve_customcuda_batched
 from .measurements import get_operator
 
 
@@ -103,7 +103,7 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
 
 
 def conditional_sampler_batched(net, noise, measurements, operators, num_steps=18, sigma_min=None, sigma_max=None,
-                                rho=7, solver="heun", slot_base=0, **other_args):
+                                rho=7, solver="heun", slot_base=0, batched_cg=True, **other_args):
     """B independent images advanced in lock-step (BASELINE.json config 2, "batch = 8"): every guidance call runs
     ONE UNet forward and ONE UNet input-VJP over the whole batch, while the per-image Free Hunch work (covariance
     updates, CG solve, branch) runs concurrently on one HIP stream + host thread + scratch context per image.
@@ -179,7 +179,16 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             x0_mean, _ = net(x_t, sigma)
         t0 = _tick("fwd", t0)
         x_det, m_det = x_t.detach(), x0_mean.detach()
-        mats = torch.cat(fan_out(lambda b: mechs[b].fh_solve(x_det[b:b + 1], m_det[b:b + 1], ys[b], sigma, net)), 0)
+        if batched_cg:
+            # covariance updates per image on their own streams, then ONE kernel sequence solves all B systems
+            fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net), x_det[b:b + 1])[1])
+            infos = []
+            mats = solve_customcuda_batched(operators, ys, [m_det[b:b + 1] for b in range(B)],
+                                            [mm.covariance_model for mm in mechs], o["max_rtol"], t, infos)
+            for b in range(B):
+                mechs[b]._rec = dict(infos[b])
+        else:
+            mats = torch.cat(fan_out(lambda b: mechs[b].fh_solve(x_det[b:b + 1], m_det[b:b + 1], ys[b], sigma, net)), 0)
         t0 = _tick("solve", t0)
         (g,) = torch.autograd.grad((mats * x0_mean).sum(), x_t)
         t0 = _tick("vjp", t0)

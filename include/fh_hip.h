@@ -116,6 +116,19 @@ typedef struct fh_problem {
   const double* tap2_w;
 } fh_problem;
 
+/* Per-image covariance pointers of a batched solve: B images share the operator, the tap lists, m, ldm and
+ * sigma_y2 of an fh_problem (whose D, r, B, M, mask fields are then ignored) and differ in these. */
+#define FH_MAX_BATCH 16
+typedef struct fh_batch {
+  int32_t nimg;
+  int32_t pad;
+  const double* D[FH_MAX_BATCH];
+  const double* r[FH_MAX_BATCH];
+  const double* B[FH_MAX_BATCH];
+  const double* M[FH_MAX_BATCH];
+  const double* mask[FH_MAX_BATCH];
+} fh_batch;
+
 typedef struct fh_cg_info {
   int32_t niter;
   int32_t optimal;
@@ -129,6 +142,12 @@ int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, v
  * (||r|| <= max(rtol*||b||, atol) -> optimal; pAp <= 1e-16 -> break; maxiter).  Blocks. */
 int fh_cg_solve(fh_context* ctx, const fh_problem* p, const double* b, double* x, double rtol, double atol,
                 int maxiter, fh_cg_info* info_host, void* stream);
+/* The same for per->nimg independent systems advanced together (one kernel sequence serves all images; an image
+ * that has met its stopping rule is skipped by every kernel).  b, x are [nimg][n]; rtol_host, info_host are
+ * [nimg] host arrays; the context must have been created with planes_max >= 3 * nimg.  Each image follows exactly
+ * the single-image iteration (same arithmetic, same stopping rule). */
+int fh_cg_solve_batched(fh_context* ctx, const fh_problem* shared, const fh_batch* per, const double* b, double* x,
+                        const double* rtol_host, double atol, int maxiter, fh_cg_info* info_host, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * UNet kernels (float32, activations NHWC [N][H][W][C] in HBM).  They replace the PyTorch modules of
