@@ -34,13 +34,13 @@ struct RtolArr {
 // ------------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <bool BT>
+template <bool BT, int T>  // T x T MFMA tiles (16x16) per wave: workgroup tile 32T x 32T
 __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                   int ldc, int64_t sA, int64_t sB, int64_t sC,
                                                   const fh_cg_state* __restrict__ states, int rows_per_plane) {
-  IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * 32) / rows_per_plane) / 3);
-  constexpr int BM = 32, BN = 32, BK = 32, LD = BK + 2;
+  constexpr int BM = 32 * T, BN = 32 * T, BK = 32, LD = BK + 2;
+  IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * BM) / rows_per_plane) / 3);
   __shared__ double As[2][BM][LD];
   __shared__ double Bs[2][BN][LD];
   A += sA * blockIdx.z;
@@ -48,43 +48,54 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   C += sC * blockIdx.z;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 16;
+  const int wm = (wave >> 1) * 16 * T, wn = (wave & 1) * 16 * T;
   const int li = lane & 15, lk = lane >> 4;
-  double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  const int srow = tid >> 3, sseg = (tid & 7) * 4;  // staging: 32 rows x 8 segments of 4 doubles
-  double ra[4], rb[4];
-  auto load_chunk = [&](int k0) {  // global -> registers (issued one chunk ahead of its use)
-    const int gm = m0 + srow;
+  double4_t acc[T][T];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int gk = k0 + sseg + e;
-      ra[e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
-    }
-    if (BT) {
-      const int gn = n0 + srow;
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // staging: BM rows x 32 k per operand = 4*T doubles per thread: row = (tid >> 3) + 32 * q, k segment (tid & 7) * 4
+  const int srow = tid >> 3, sseg = (tid & 7) * 4;
+  double ra[T][4], rb[T][4];
+  auto load_chunk = [&](int k0) {  // global -> registers (issued one chunk ahead of its use)
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      const int gm = m0 + srow + 32 * q;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gk = k0 + sseg + e;
-        rb[e] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+        ra[q][e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
       }
-    } else {
-      const int gk = k0 + srow;  // srow indexes k here, sseg the n segment
+      if (BT) {
+        const int gn = n0 + srow + 32 * q;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int gn = n0 + sseg + e;
-        rb[e] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
+        for (int e = 0; e < 4; ++e) {
+          const int gk = k0 + sseg + e;
+          rb[q][e] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+        }
+      } else {
+        const int gk = k0 + srow;  // srow indexes k here, (sseg + 32 q) the n segment
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int gn = n0 + sseg + 32 * q + e;
+          rb[q][e] = (gn < N && gk < K) ? B[(int64_t)gk * ldb + gn] : 0.0;
+        }
       }
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) As[buf][srow][sseg + e] = ra[e];
-    if (BT) {
+    for (int q = 0; q < T; ++q) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Bs[buf][srow][sseg + e] = rb[e];
-    } else {
+      for (int e = 0; e < 4; ++e) As[buf][srow + 32 * q][sseg + e] = ra[q][e];
+      if (BT) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Bs[buf][sseg + e][srow] = rb[e];
+        for (int e = 0; e < 4; ++e) Bs[buf][srow + 32 * q][sseg + e] = rb[q][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[buf][sseg + 32 * q + e][srow] = rb[q][e];
+      }
     }
   };
   load_chunk(0);
@@ -96,19 +107,30 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
     if (more) load_chunk(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      const double a = As[buf][wm + li][kk + lk];
-      const double b = Bs[buf][wn + li][kk + lk];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      double a[T], b[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) a[i] = As[buf][wm + 16 * i + li][kk + lk];
+#pragma unroll
+      for (int j = 0; j < T; ++j) b[j] = Bs[buf][wn + 16 * j + li][kk + lk];
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
   }
-  const int gn = n0 + wn + li;
-  if (gn < N) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gm = m0 + wm + lk + 4 * r;
-      if (gm < M) C[(int64_t)gm * ldc + gn] = acc[r];
+  for (int j = 0; j < T; ++j) {
+    const int gn = n0 + wn + 16 * j + li;
+    if (gn >= N) continue;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gm = m0 + wm + 16 * i + lk + 4 * r;
+        if (gm < M) C[(int64_t)gm * ldc + gn] = acc[i][j][r];
+      }
     }
   }
 }
@@ -120,15 +142,31 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
   const double* b1 = inverse ? ctx->basis_t : ctx->basis;
   // pass 1 (along W): T[r][k] = sum_n X[r][n] * b1[k][n]
   {
-    dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
-    hipLaunchKernelGGL(k_gemm_f64<true>, grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+    // 64x64 workgroup tiles (2x2 MFMA tiles per wave, half the LDS/global traffic per flop) once they still give
+    // >= 1.5 workgroups per CU; otherwise 32x32 tiles to keep the chip populated
+    const bool big = (int64_t)((S + 63) / 64) * ((planes * S + 63) / 64) >= 384;
+    if (big) {
+      dim3 grid((S + 63) / 64, (planes * S + 63) / 64, 1);
+      hipLaunchKernelGGL((k_gemm_f64<true, 2>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                         (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+    } else {
+      dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
+      hipLaunchKernelGGL((k_gemm_f64<true, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                         (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+    }
   }
   // pass 2 (along H), per plane: Y[k][w] = sum_n b1[k][n] * T[n][w]
   {
-    dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
-    hipLaunchKernelGGL(k_gemm_f64<false>, grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    const bool big = (int64_t)((S + 63) / 64) * ((S + 63) / 64) * planes >= 384;
+    if (big) {
+      dim3 grid((S + 63) / 64, (S + 63) / 64, planes);
+      hipLaunchKernelGGL((k_gemm_f64<false, 2>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                         S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    } else {
+      dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
+      hipLaunchKernelGGL((k_gemm_f64<false, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                         S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    }
   }
   FH_LAUNCH_CHECK();
   return 0;
@@ -531,11 +569,11 @@ constexpr int kMaxTaps = 1024;
 __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in, double* __restrict__ out,
                                                    const int* __restrict__ tdy, const int* __restrict__ tdx,
                                                    const double* __restrict__ tw, int ntaps, int S, int halo,
-                                                   int adjoint, int up, const double* __restrict__ add,
+                                                   int halo_x, int adjoint, int up, const double* __restrict__ add,
                                                    double add_scale, const fh_cg_state* __restrict__ states) {
   IMG_GUARD(states, blockIdx.z / 3);
   extern __shared__ __align__(16) double tile[];  // [sh*sw] tile | [ntaps] weights | [ntaps] int offsets
-  const int sw = 32 + 2 * halo, sh = 16 + 2 * halo;
+  const int sw = 32 + 2 * halo_x, sh = 16 + 2 * halo;  // halo = rows (dy extent), halo_x = columns (dx extent)
   double* s_w = tile + sw * sh;
   int* s_off = reinterpret_cast<int*>(s_w + ntaps);
   const int plane = blockIdx.z;
@@ -549,7 +587,7 @@ __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in
   }
   for (int idx = threadIdx.x; idx < sw * sh; idx += 256) {
     const int ly = idx / sw, lx = idx % sw;
-    int gy = (oy0 + ly - halo) % S, gx = (ox0 + lx - halo) % S;
+    int gy = (oy0 + ly - halo) % S, gx = (ox0 + lx - halo_x) % S;
     gy += gy < 0 ? S : 0;
     gx += gx < 0 ? S : 0;
     double v;
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in
   __syncthreads();
   const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // ly in [0,8): rows ly, ly+8
   double a0 = 0, a1 = 0;
-  const double* q0 = tile + (ly + halo) * sw + lx + halo;
+  const double* q0 = tile + (ly + halo) * sw + lx + halo_x;
   const double* q1 = q0 + 8 * sw;
   int t = 0;
   for (; t + 3 < ntaps; t += 4) {
@@ -626,17 +664,21 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
                        const double* w, int ntaps, int halo, int planes, int stride, int adjoint, const double* add,
                        double add_scale, const fh_cg_state* done, hipStream_t st) {
   const int S = ctx->S;
-  if (stride < 1 || S % stride != 0 || halo < 0 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
+  if (stride < 1 || S % stride != 0 || halo < -133 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
   if (!adjoint && stride > 1) {
     const int So = S / stride;
     const int64_t total = (int64_t)planes * So * So;
     hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, dy, dx, w,
                        ntaps, S, stride, planes, add, add_scale, done);
   } else {
-    const size_t lds = (size_t)(32 + 2 * halo) * (16 + 2 * halo) * sizeof(double) + (size_t)ntaps * 12;
+    // halo = max(|dy|,|dx|); negative values encode 1-D tap lists: -(h+1) = column kernel (dx = 0), -(h+101) = row kernel
+    int hy = halo, hx = halo;
+    if (halo <= -101) hy = 0, hx = -halo - 101;
+    else if (halo < 0) hy = -halo - 1, hx = 0;
+    const size_t lds = (size_t)(32 + 2 * hx) * (16 + 2 * hy) * sizeof(double) + (size_t)ntaps * 12;
     if (lds > 64 * 1024) return FH_ESIZE;
     dim3 grid((S + 31) / 32, (S + 15) / 16, planes);
-    hipLaunchKernelGGL(k_conv_tile, grid, dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, halo, adjoint,
+    hipLaunchKernelGGL(k_conv_tile, grid, dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, hy, hx, adjoint,
                        adjoint ? stride : 1, add, add_scale, done);
   }
   FH_LAUNCH_CHECK();

@@ -83,7 +83,8 @@ int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k
  *                 (out is [planes][S/stride][S/stride]; stride 4 = blur + decimate of the SR solver)
  *   adjoint = 1:  out[p][i][j] = sum_t w[t] * up(in)[(i + dy[t]) mod S][(j + dx[t]) mod S]
  *                 (in is [planes][S/stride][S/stride], zero-inserted on the fly)
- * halo = max(|dy|, |dx|) over the taps (<= 32).
+ * halo = max(|dy|, |dx|) over the taps (<= 32); 1-D tap lists may pass -(h+1) (column kernel, all dx = 0) or
+ * -(h+101) (row kernel, all dy = 0) so that only the needed halo is staged.
  * Equals ifft2(FB * fft2(x)).real / ifft2(conj(FB) * fft2(x)).real of the reference. */
 int fh_conv_circ(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
                  const double* w, int ntaps, int halo, int planes, int stride, int adjoint, void* stream);
