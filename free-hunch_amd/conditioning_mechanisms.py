@@ -21,7 +21,7 @@ import torch
 from torch.autograd import grad
 
 from . import _lib
-from .covariance import CovarianceHessianBFGS, CovarianceHessianBFGSDCT
+from .covariance import CovarianceHessianBFGS, CovarianceHessianBFGSDCT, ScalarCovariance
 
 F64 = torch.float64
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -98,7 +98,7 @@ def _sigma_y2(operator):
     return float((s ** 2).item())
 
 
-def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out=None):
+def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out=None, rtol=None):
     """mat = A^T (A C A^T + sigma_y^2 I)^-1 (y - A x0_mean), float64, on the device."""
     cov = covariance_model
     ctx = cov.ctx
@@ -119,7 +119,7 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
         b = ctx.axpby(1.0, y64, -1.0, ax, ax)
     sol = torch.empty_like(b)
     info = _lib.FhCgInfo()
-    rtol = rtol_func(sigma_t, max_rtol)
+    rtol = rtol_func(sigma_t, max_rtol) if rtol is None else rtol
     _lib.check(ctx.lib.fh_cg_solve(ctx.h, C.byref(prob), b.data_ptr(), sol.data_ptr(), rtol, 0.0, 5000,
                                    C.byref(info), _lib.stream()), "fh_cg_solve")
     if info.niter == (5000 if name == "inpainting" else 2000):  # the reference's (inconsistent) guards
@@ -238,9 +238,8 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self.space_step_update_threshold = argv["space_step_update_threshold"]
         self.space_step_update_lower_threshold = argv["space_step_update_lower_threshold"]
         self.pigdm_posthoc_scaling = pigdm_posthoc_scaling
-        if argv.get("use_analytic_var_at_end", False):
-            raise NotImplementedError("use_analytic_var_at_end needs the scalar-variance scipy solver (next row)")
-        # the reference loads this file unconditionally (:225-226); keep the dependency visible
+        self.use_analytic_var_at_end = argv.get("use_analytic_var_at_end", False)
+        # the reference loads this file unconditionally (:225-226)
         self.recon_mse = torch.load(os.path.join(_DATA, "recon_mse.pt"), weights_only=True)
         self.mle_sigma_thres = 0.2
         self.trace = []  # per call: niter, branch, k (not in the reference; used by the parity tests)
@@ -261,9 +260,21 @@ class BFGSOnlineUpdate(ConditioningMechanism):
     # The call is split in two so that a batch of independent images can share ONE UNet forward and ONE UNet
     # input-VJP (sampler.conditional_sampler_batched): fh_solve = covariance updates + CG solve for one image,
     # fh_finish = the 0.2-std branch and the history append.
+    def analytic_now(self, sigma):
+        return bool(self.use_analytic_var_at_end and float(sigma) < self.mle_sigma_thres)
+
     def fh_solve(self, x_det, m_det, y, sigma, model=None):
         self.fh_update(x_det, m_det, sigma, model)
         info = []
+        if self.analytic_now(sigma):
+            # :273-276 - scalar variance from recon_mse.pt; the reference's Fourier closed forms (:357, :454, :608) are
+            # A^T (theta A A^T + s^2 I)^-1 (y - A x0) exactly; here the same system goes through CG with C = theta I
+            idx = (self.recon_mse["sigmas"].double() - float(sigma)).abs().argmin()
+            theta = float(self.recon_mse["mse_list"][idx])
+            scal = ScalarCovariance(theta, self.data_dim, m_det.device, self.covariance_model.ctx_slot)
+            mat = solve_customcuda(self.forward_operator, y, m_det, scal, 1.0, float(sigma), info, rtol=1e-10)
+            self._rec = dict(info[0], analytic=True)
+            return mat
         mat = choose_solver(self.forward_operator.name, self.forward_operator, y, m_det,
                             covariance_model=self.covariance_model, method=self.solver_type, max_rtol=self.max_rtol,
                             sigma_t=float(sigma), info_out=info)
@@ -294,7 +305,10 @@ class BFGSOnlineUpdate(ConditioningMechanism):
     def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma):
         cm, rec, s = self.covariance_model, self._rec, float(sigma)
         sig2 = torch.as_tensor(sigma, dtype=F64, device=m_det.device).pow(2)
-        if (p_y_xt_grad * sig2).std() > self.denoiser_mean_error_threshold:
+        if rec.get("analytic"):  # :277-278: always the VJP form
+            p_y_xt_grad = p_y_xt_grad * self.cond_scaling
+            rec["branch"] = "vjp"
+        elif (p_y_xt_grad * sig2).std() > self.denoiser_mean_error_threshold:
             p_y_xt_grad = cm.denoiser_cov_vector_dot(mat.detach(), use_cuda=True) * self.cond_scaling / sig2
             rec["branch"] = "cov"
         else:

@@ -92,6 +92,7 @@ class CovarianceHessianBFGS:
         self.S, self.data_dim = S, data_dim
         self.max_vector_count = max_vector_count
         self.project_to_diagonal = project_to_diagonal
+        self.ctx_slot = ctx_slot
         self.ctx = _lib.Context.get(S, 3, _lib_max_cols(), ctx_slot)
         self.m_cap = m_cap
         d = data_dim
@@ -291,3 +292,19 @@ class CovarianceHessianBFGSDCT(CovarianceHessianBFGS):
 
     def _bwd(self, v, out=None):
         return self.ctx.dct2d(v.view(3, self.S, self.S), inverse=True).view(-1)
+
+
+class ScalarCovariance:
+    """C = theta * I in image space - the covariance behind the reference's scalar-variance closed forms
+    (`use_analytic_var_at_end`, conditioning_mechanisms.py:273-278).  Exposes just what the solver reads."""
+
+    use_dct = False
+
+    def __init__(self, theta, data_dim, device, ctx_slot=0):
+        self.device = torch.device(device)
+        self.data_dim = data_dim
+        self.S = int(round(math.sqrt(data_dim / 3)))
+        self.ctx = _lib.Context.get(self.S, 3, _lib_max_cols(), ctx_slot)
+        self.famC = _Family.__new__(_Family)
+        self.famC.m, self.famC.B = 0, torch.zeros(1, dtype=F64, device=self.device)
+        self.C = _Rep(torch.full((data_dim,), float(theta), dtype=F64, device=self.device), 1)

@@ -179,7 +179,7 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             x0_mean, _ = net(x_t, sigma)
         t0 = _tick("fwd", t0)
         x_det, m_det = x_t.detach(), x0_mean.detach()
-        if batched_cg:
+        if batched_cg and not mechs[0].analytic_now(sigma):
             # covariance updates per image on their own streams, then ONE kernel sequence solves all B systems
             fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net), x_det[b:b + 1])[1])
             infos = []

@@ -470,6 +470,26 @@ def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None):
     return mat
 
 
+def analytic_mat(op, y, x0_mean, theta):
+    """Scalar-variance closed forms used when `use_analytic_var_at_end` (conditioning_mechanisms.py:357-358,
+    :454-455, :608-610): mat = A^T (theta A A^T + sigma_s^2 I)^-1 (y - A x0_mean) evaluated in Fourier space."""
+    if op.name == "inpainting":
+        s2 = op.sigma_s.clip(min=0.001).pow(2)
+        return (op.mask * y - op.mask * x0_mean) / (s2 + theta)
+    FB, FBC, F2B, _ = op.pre_calculated
+    fft2, ifft2 = torch.fft.fft2, torch.fft.ifft2
+    if op.name in ("gaussian_blur", "motion_blur"):
+        s2 = op.sigma_s.clip(min=0.001).pow(2)
+        return ifft2(fft2(y - ifft2(FB * fft2(x0_mean))) / (s2 + theta * F2B) * FBC).real
+    s2 = op.sigma_s.clip(min=0.001).clip(min=1e-2).pow(2)
+    sf = op.scale_factor
+    blocks = torch.stack(torch.chunk(F2B, sf, dim=2), dim=4)          # utils_sisr.splits :9-19
+    blocks = torch.cat(torch.chunk(blocks, sf, dim=3), dim=4)
+    invW = torch.mean(blocks, dim=-1)
+    res = fft2(y - decimate(ifft2(FB * fft2(x0_mean)), sf)) / (s2 + theta * invW)
+    return ifft2(FBC * res.repeat(1, 1, sf, sf)).real
+
+
 # --------------------------------------------------------------------------
 # a6  BFGSOnlineUpdate   conditioning_mechanisms.py:190-294 (+ base class :38-50)
 # --------------------------------------------------------------------------
@@ -478,7 +498,7 @@ class OracleFreeHunch:
                  image_base_covariance="dct_diagonal", data_dir=None, max_vector_count=100000,
                  project_to_diagonal=False, do_space_updates=True, denoiser_mean_error_threshold=0.2,
                  use_analytical_score_time_update=True, space_step_update_threshold=10.0,
-                 space_step_update_lower_threshold=1.0, max_rtol=1.0):
+                 space_step_update_lower_threshold=1.0, max_rtol=1.0, use_analytic_var_at_end=False, recon_mse=None):
         self.cond_scaling, self.op, self.clip = cond_scaling, forward_operator, clip_x0_mean
         self.cov = make_covariance(image_base_covariance, data_dir, float(init_noise_variance), data_dim,
                                    max_vector_count, project_to_diagonal)
@@ -487,6 +507,7 @@ class OracleFreeHunch:
         self.analytic_score = use_analytical_score_time_update
         self.upper, self.lower = space_step_update_threshold, space_step_update_lower_threshold
         self.max_rtol = max_rtol
+        self.analytic_end, self.recon_mse = use_analytic_var_at_end, recon_mse  # :224-226, threshold 0.2 (:227)
         self.sigmas, self.xs, self.means = [], [], []
         self.trace = []  # one dict per call: niter, branch, k ...
 
@@ -523,9 +544,16 @@ class OracleFreeHunch:
         with torch.no_grad():
             mat = solve_mat(self.op, y, x0.detach(), self.cov, self.max_rtol, s, info)
         rec.update(info[0])
+        analytic = self.analytic_end and s < 0.2
+        if analytic:  # :273-278
+            idx = (self.recon_mse["sigmas"].double() - s).abs().argmin()
+            mat = analytic_mat(self.op, y, x0.detach(), self.recon_mse["mse_list"][idx].double())
         (g,) = torch.autograd.grad((mat.detach() * x0).sum(), x_t)
         sig2 = torch.as_tensor(sigma, dtype=torch.float64) ** 2
-        if (g * sig2).std() > self.err_thr:  # :283-285
+        if analytic:
+            g = g * self.cond_scaling
+            rec["branch"] = "vjp"
+        elif (g * sig2).std() > self.err_thr:  # :283-285
             g = self.cov.denoiser_cov_vector_dot(mat.detach()) * self.cond_scaling / sig2
             rec["branch"] = "cov"
         else:
