@@ -222,6 +222,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    import __graft_entry__
+    if local == 0:
+        __graft_entry__.build()  # no-op when free-hunch_amd/libfh_hip.so is up to date
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:

@@ -346,7 +346,7 @@ def test_trajectory_free_running_vs_reference_golden(dev, gold, tag, unet, tmp_p
 
 
 TF_TAGS = ["gb_heun10", "mb_heun10", "sr_heun10", "ip_euler20", "gb_heun10_nospace", "gb_heun10_readme",
-           "gb_heun10_identity", "sr_heun10+analytic", "ip_euler20+analytic"]
+           "gb_heun10_identity", "sr_heun10+analytic", "ip_euler20+analytic", "sr_heun10+netscore", "sr_heun10+project"]
 
 
 @pytest.mark.parametrize("tag", TF_TAGS)
@@ -361,12 +361,18 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     from test_oracle_golden import _mk_op
     g = gold("trajectories")
     analytic = tag.endswith("+analytic")  # use_analytic_var_at_end = true (scalar-variance closed form below sigma 0.2)
+    netscore = tag.endswith("+netscore")  # use_analytical_score_time_update = false (extra UNet call at x_prev, :252-254)
+    project = tag.endswith("+project")    # project_to_diagonal = true (:274-277, incl. the Hessian quirk)
     tag = tag.split("+")[0]
     p = tag + "__"
     torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
     over = eval(str(g[p + "over"]))
     if analytic:
         over = {**over, "use_analytic_var_at_end": True}
+    if netscore:
+        over = {**over, "use_analytical_score_time_update": False}
+    if project:
+        over = {**over, "project_to_diagonal": True}
     recon = torch.load(os.path.join(ROOT, "free-hunch_amd", "data", "recon_mse.pt"), weights_only=True)
     opname = str(g[p + "op"])
     s_img, s_noise = (int(v) for v in g[p + "seeds"])
@@ -385,7 +391,8 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
                                         data_dir=str(tmp_path), do_space_updates=kw["do_space_updates"],
                                         space_step_update_threshold=kw["space_step_update_threshold"],
                                         space_step_update_lower_threshold=kw["space_step_update_lower_threshold"],
-                                        use_analytic_var_at_end=analytic, recon_mse=recon)
+                                        use_analytic_var_at_end=analytic, recon_mse=recon,
+                                        use_analytical_score_time_update=not netscore, project_to_diagonal=project)
             self.h = BFGSOnlineUpdate(1.0, hop, False, 1, torch.as_tensor(v0), d, solver_type="customcuda",
                                       data_dir=str(tmp_path), **{k: v for k, v in kw.items() if k not in
                                                                  ("conditioning_mechanism", "cond_scaling",
