@@ -149,7 +149,37 @@ def roofline_cov_apply(device, m=32, iters=200):
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
 
 
-def cpu_baseline(arch, operator_name, num_steps, data_dir, calls=5):
+def roofline_conv_mfma(device, iters=20):
+    """The dominant UNet kernel: 3x3 conv 128 -> 128 on 8 x 256 x 256 NHWC fp32 (k_conv_igemm<2,2>), events on the
+    launch stream; peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)."""
+    from free_hunch_amd import _lib
+    lib = _lib.load()
+    N, H, W, Ci, Co, k = 8, 256, 256, 128, 128, 3
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, H, W, Ci, generator=g).to(device)
+    w = (torch.randn(Co, k * k, Ci, generator=g) * 0.03).to(device)
+    b = torch.zeros(Co, device=device)
+    out = torch.empty(N, H, W, Co, device=device)
+    f = lambda: _lib.check(lib.fh_conv2d_nhwc(x.data_ptr(), w.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, 1, N,
+                                              H, W, Ci, Co, k, k, 1, 1, _lib.stream()), "conv")
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * N * H * W * Ci * Co * k * k
+    ach = flops / sec / 1e12
+    return {"bound": "mfma", "kernel": "k_conv_igemm<2,2> 3x3 128->128 on 8x256x256 NHWC fp32 (v_mfma_f32_32x32x2_f32)",
+            "achieved": round(ach, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4), "traffic": None,
+            "flops_per_launch": flops, "us_per_launch": round(sec * 1e6, 1)}
+
+
+def cpu_baseline(arch, operator_name, num_steps, data_dir, calls=4):
     """The oracle (port of the reference path) on the host cores: `calls` guidance calls of one image, extrapolated."""
     from oracle import fh_oracle as fo, unet_oracle as uo
     import scipy.io
@@ -213,7 +243,7 @@ def main():
     ap.add_argument("--solver", default="heun")
     ap.add_argument("--unet-backend", default=os.environ.get("FH_UNET_BACKEND", "hip"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-calls", type=int, default=5)
+    ap.add_argument("--cpu-calls", type=int, default=4)
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -278,6 +308,7 @@ def main():
                        "cg_iters_per_image_last_step": getattr(run_batch, "cg_iters", None)},
         }
         line["roofline"] = roofline_cov_apply(device)
+        line["roofline_unet_conv"] = roofline_conv_mfma(device)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch, a.operator, a.num_steps, data_dir, a.cpu_calls)
         print(json.dumps(line), flush=True)
