@@ -252,14 +252,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    import __graft_entry__
-    if local == 0:
-        __graft_entry__.build()  # no-op when free-hunch_amd/libfh_hip.so is up to date
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
+    import __graft_entry__
+    if local == 0:
+        __graft_entry__.build()  # no-op when free-hunch_amd/libfh_hip.so is up to date
+    if world > 1:
+        dist.barrier()  # the other ranks load the library only after rank 0 has (re)built it
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     data_dir = os.path.join(ROOT, "free-hunch_amd", "data")
