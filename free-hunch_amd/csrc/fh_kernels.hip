@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
                                                   const fh_cg_state* __restrict__ states, int rows_per_plane) {
   constexpr int BM = 32 * T, BN = 32 * T, BK = 32, LD = BK + 2;
   IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * BM) / rows_per_plane) / 3);
-  __shared__ double As[2][BM][LD];
-  __shared__ double Bs[2][BN][LD];
+  __shared__ __align__(16) double As[2][BM][LD];
+  __shared__ __align__(16) double Bs[2][BN][LD];
   A += sA * blockIdx.z;
   B += sB * blockIdx.z;
   C += sC * blockIdx.z;
@@ -58,10 +58,22 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   // staging: BM rows x 32 k per operand = 4*T doubles per thread: row = (tid >> 3) + 32 * q, k segment (tid & 7) * 4
   const int srow = tid >> 3, sseg = (tid & 7) * 4;
   double ra[T][4], rb[T][4];
+  // full tiles (every DCT size that is a multiple of 64/32) take 16-byte loads; ragged edges fall back to guarded scalars
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0) && ((lda | ldb) % 2 == 0);
   auto load_chunk = [&](int k0) {  // global -> registers (issued one chunk ahead of its use)
 #pragma unroll
     for (int q = 0; q < T; ++q) {
       const int gm = m0 + srow + 32 * q;
+      if (full) {
+        const double2* pa = reinterpret_cast<const double2*>(A + (int64_t)gm * lda + k0 + sseg);
+        const double2 a0 = pa[0], a1 = pa[1];
+        ra[q][0] = a0.x, ra[q][1] = a0.y, ra[q][2] = a1.x, ra[q][3] = a1.y;
+        const double2* pb = BT ? reinterpret_cast<const double2*>(B + (int64_t)(n0 + srow + 32 * q) * ldb + k0 + sseg)
+                               : reinterpret_cast<const double2*>(B + (int64_t)(k0 + srow) * ldb + n0 + sseg + 32 * q);
+        const double2 b0 = pb[0], b1 = pb[1];
+        rb[q][0] = b0.x, rb[q][1] = b0.y, rb[q][2] = b1.x, rb[q][3] = b1.y;
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gk = k0 + sseg + e;
@@ -87,11 +99,11 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < T; ++q) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) As[buf][srow + 32 * q][sseg + e] = ra[q][e];
+      *reinterpret_cast<double2*>(&As[buf][srow + 32 * q][sseg]) = make_double2(ra[q][0], ra[q][1]);
+      *reinterpret_cast<double2*>(&As[buf][srow + 32 * q][sseg + 2]) = make_double2(ra[q][2], ra[q][3]);
       if (BT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[buf][srow + 32 * q][sseg + e] = rb[q][e];
+        *reinterpret_cast<double2*>(&Bs[buf][srow + 32 * q][sseg]) = make_double2(rb[q][0], rb[q][1]);
+        *reinterpret_cast<double2*>(&Bs[buf][srow + 32 * q][sseg + 2]) = make_double2(rb[q][2], rb[q][3]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) Bs[buf][sseg + 32 * q + e][srow] = rb[q][e];
