@@ -27,6 +27,18 @@ def _pad_to(n, m):
     return (n + m - 1) // m * m
 
 
+def _wino(w):
+    """[rows][ky][kx][K] -> [4][rows][ky][K]: u = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2) over kx"""
+    w0, w1, w2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
+    return torch.stack([w0, (w0 + w1 + w2) / 2, (w0 - w1 + w2) / 2, w2], 0).contiguous()
+
+
+def _use_wino(N, H, W, K, rows_out):
+    """Measured on MI355X: the fused F(2,3) kernel wins 1.10-1.13x once K = Cin >= 256 and the tile grid fills the chip;
+    below that the direct kernel (or split-K) is faster."""
+    return W % 2 == 0 and K % 16 == 0 and K >= 256 and N * H * (W // 2) >= 16384 and rows_out >= 64
+
+
 class _Conv:
     def __init__(self, w, b):
         co, ci = w.shape[0], w.shape[1]
@@ -39,6 +51,11 @@ class _Conv:
         wd = torch.zeros(ci, kh * kw, self.co_p, dtype=torch.float32, device=w.device)
         wd[:, :, :co] = w4.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, kh * kw, co)
         self.wf, self.wd, self.b = wf.contiguous(), wd.contiguous(), b.float().contiguous()
+        # F(2,3) Winograd copies along kx, [4][rows][3 ky][K]: used for the large 3x3 layers (fh_conv3x3_wino_nhwc)
+        self.wu_f = self.wu_d = None
+        if kh == 3 and kw == 3:
+            self.wu_f = _wino(wf.reshape(co, 3, 3, self.ci_p))
+            self.wu_d = _wino(wd.reshape(ci, 3, 3, self.co_p))
 
 
 class HipOps:
@@ -62,6 +79,11 @@ class HipOps:
         pad = c.kh // 2
         out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
         b = c.b if bias_override is None else bias_override
+        if c.wu_f is not None and _use_wino(N, H, W, Ci, c.co):
+            _lib.check(self.lib.fh_conv3x3_wino_nhwc(x.data_ptr(), c.wu_f.data_ptr(), b.data_ptr(),
+                                                     None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
+                                                     Ci, c.co, _lib.stream()), "fh_conv3x3_wino_nhwc")
+            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
@@ -78,6 +100,11 @@ class HipOps:
             gp[..., :Co] = g
             g = gp
         out = torch.empty(N, H, W, c.ci, dtype=torch.float32, device=g.device)
+        if c.wu_d is not None and _use_wino(N, H, W, c.co_p, c.ci):
+            _lib.check(self.lib.fh_conv3x3_wino_nhwc(g.data_ptr(), c.wu_d.data_ptr(), None,
+                                                     None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
+                                                     c.co_p, c.ci, _lib.stream()), "fh_conv3x3_wino_nhwc(dgrad)")
+            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None
         _lib.check(self.lib.fh_conv2d_nhwc(g.data_ptr(), c.wd.data_ptr(), None,

@@ -159,3 +159,54 @@ def test_unet_hip_vs_reference_golden(dev, gold):
         cot = inputs.randn(D.shape, seed + 200 + j).to(D.dtype).to(dev)
         (vjp,) = torch.autograd.grad((cot * D).sum(), xt)
         assert rel(vjp, torch.from_numpy(g[f"vjp_{j}"]).to(dev)) < 2e-3
+
+
+def wino_weights(w):
+    """[Cout][Cin][3][3] -> [4][Cout][3][Cin] F(2,3) transform along kx (see fh_conv3x3_wino_nhwc)."""
+    w0, w1, w2 = w[..., 0], w[..., 1], w[..., 2]  # [Co][Ci][ky]
+    u = torch.stack([w0, (w0 + w1 + w2) / 2, (w0 - w1 + w2) / 2, w2], 0)  # [4][Co][Ci][ky]
+    return u.permute(0, 1, 3, 2).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64, 128, 128), (2, 16, 32, 64, 96), (1, 256, 256, 32, 128), (1, 9, 14, 32, 6),
+                                   (3, 8, 8, 160, 64)])
+def test_conv_winograd_vs_torch(dev, shape):
+    L, lib = _lib()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    res = torch.randn(N, Co, H, W, generator=g).to(dev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + res.double()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    rn = res.permute(0, 2, 3, 1).contiguous()
+    wu = wino_weights(w)
+    out = torch.empty(N, H, W, Co, device=dev)
+    L.check(lib.fh_conv3x3_wino_nhwc(xn.data_ptr(), wu.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), N, H, W,
+                                     Ci, Co, L.stream()), "wino")
+    # F(2,3) has ~2x the error constant of the direct fp32 sum
+    assert rel(out.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_unet_ffhq256_hip_vs_torch_backend(dev):
+    """The benchmark architecture at full size (exercises the 128x128 / Winograd / split-K kernel choices): forward and
+    input-VJP of the HIP backend against the PyTorch-ROCm backend, same seeded weights."""
+    from free_hunch_amd import unet as hu
+    cfg = hu.FFHQ256
+    sd = hu.seeded_state(cfg, 0)
+    outs = []
+    x = (inputs.randn((1, 3, 256, 256), 8, torch.float32) * 0.5).to(dev)
+    t = torch.tensor([300], device=dev)
+    cot = inputs.randn((1, 6, 256, 256), 9, torch.float32).to(dev)
+    for backend in ("hip", "torch"):
+        m = hu.UNetModel(cfg, backend=backend)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        xi = x.clone().requires_grad_()
+        y = m(xi, t)
+        (gx,) = torch.autograd.grad((y * cot).sum(), xi)
+        outs.append((y.detach(), gx))
+        del m
+    assert rel(outs[0][0], outs[1][0]) < 5e-4
+    assert rel(outs[0][1], outs[1][1]) < 2e-3
