@@ -149,6 +149,42 @@ def roofline_cov_apply(device, m=32, iters=200):
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
 
 
+def roofline_dense_cov_apply(device, d=12288, iters=30):
+    """Dense-matrix covariance path (BASELINE config 3): y = C x with C a float64 (d, d) matrix at the SR
+    measurement dimension d = 12288 (1.2 GB) - one streaming pass, 8 d^2 algorithmic bytes - and the rank-2 update
+    C <- C + a u v^T + b w z^T (read + write, 16 d^2 bytes).  Events on the launch stream."""
+    from free_hunch_amd import dense
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(1, d, d, generator=g, dtype=torch.float64).to(device)
+    x, u, v = (torch.randn(1, d, generator=g, dtype=torch.float64).to(device) for _ in range(3))
+    y = torch.empty_like(x)
+    c = torch.full((1,), 1e-3, dtype=torch.float64, device=device)
+    out = torch.empty_like(A)
+
+    def timed(f):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / iters
+
+    t_mv = timed(lambda: dense.matvec(A, x, out=y))
+    t_r2 = timed(lambda: dense.rank2(A, u, v, c, v, u, c, out=out))
+    mv_bytes, r2_bytes = 8 * d * d + 16 * d, 16 * d * d + 32 * d
+    ach = mv_bytes / t_mv / 1e9
+    return {"bound": "hbm", "kernel": f"k_dense_mv (y = C x, d={d}, f64, bs=1)", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes": mv_bytes, "us_per_apply": round(t_mv * 1e6, 1),
+            "rank2_update": {"kernel": "k_dense_rank2", "achieved": round(r2_bytes / t_r2 / 1e9, 1), "unit": "GB/s",
+                             "frac": round(r2_bytes / t_r2 / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": r2_bytes,
+                             "us_per_update": round(t_r2 * 1e6, 1)}}
+
+
 def roofline_conv_mfma(device, iters=20):
     """The dominant UNet kernel: 3x3 conv 128 -> 128 on 8 x 256 x 256 NHWC fp32 (k_conv_igemm<2,2>), events on the
     launch stream; peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md)."""
@@ -311,6 +347,7 @@ def main():
         }
         line["roofline"] = roofline_cov_apply(device)
         line["roofline_unet_conv"] = roofline_conv_mfma(device)
+        line["roofline_dense_cov_apply"] = roofline_dense_cov_apply(device)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch, a.operator, a.num_steps, data_dir, a.cpu_calls)
         print(json.dumps(line), flush=True)

@@ -52,6 +52,10 @@ _SIGS = {
     "fh_conv_circ": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_void_p], C.c_int),
     "fh_amm": ([C.c_void_p, C.POINTER(FhProblem), c_dp, c_dp, C.c_void_p], C.c_int),
+    "fh_dense_matvec_scratch_doubles": ([C.c_int, C.c_int64], C.c_int64),
+    "fh_dense_matvec": ([c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_void_p], C.c_int),
+    "fh_dense_rank2": ([c_dp, c_dp, C.c_int, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double,
+                        C.c_void_p], C.c_int),
     "fh_conv2d_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
     "fh_conv3x3_wino_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),

@@ -155,25 +155,29 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // 3x3 / stride 1 / pad 1 convolution with a 1-D Winograd F(2,3) transform along W, fused into the implicit GEMM.
-//   tile = 2 horizontally adjacent outputs (W even);  for every kernel row ky the 4 input pixels d0..d3 at columns
-//   2xt-1 .. 2xt+2 of input row y+ky-1 are transformed to  v = (d0-d2, d1+d2, d2-d1, d1-d3)  while they are staged
-//   into LDS; the weights arrive pre-transformed,  u = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2)  per (co, ky, ci);
-//   four accumulator sets m_xi += V_xi U_xi^T over K = 3*Cin;   y0 = m0+m1+m2,  y1 = m1-m2-m3.
-// 4 multiplies per 2 outputs and kernel row instead of 6: 1.5x fewer MFMAs than the direct kernel at the same
-// fp32 MFMA (error constants of F(2,3) are ~2x those of the direct sum).  Workgroup = 8 waves (4 x 2): 128 tiles x 64
-// output channels, wave tile 32 tiles x 32 channels x 4 positions (64 accumulator VGPRs); K chunks of 16 channels,
-// double-buffered LDS (row stride 20 floats: conflict-free b128 reads), register prefetch.
-// wu layout: [4 positions][Cout][3 ky][Cin].
+//   tile = 2 horizontally adjacent outputs (W even).  For kernel row ky the 4 input pixels d0..d3 at columns
+//   2xt-1 .. 2xt+2 of input row y+ky-1 give  v = (d0-d2, d1+d2, d2-d1, d1-d3);  the weights arrive pre-transformed,
+//   u = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2)  per (co, ky, ci);  four accumulator sets m_xi += V_xi U_xi^T over
+//   K = 3*Cin;  y0 = m0+m1+m2,  y1 = m1-m2-m3.   4 multiplies per 2 outputs and kernel row instead of 6: 1.5x fewer
+//   MFMAs than the direct kernel at the same exact-fp32 MFMA (error constants ~2x those of the direct sum).
+// Data movement is what decides whether the 1.5x materialises, so the input is staged RAW: every pixel of the
+// workgroup's tile range is loaded once per chunk (d0 / d3 of a tile are its neighbours' pixels) and the transform
+// happens in registers when the MFMA fragments are read (4 b128 reads + 16 VALU per 4 fragments - the same read count
+// as four pre-transformed matrices would need).  Workgroup = 8 waves (4 x 2): 256 tiles x 64 output channels; wave tile
+// 64 tiles x 32 channels x 4 positions (128 accumulator VGPRs); K chunks of 16 channels, double-buffered LDS (row
+// stride 20 floats: conflict-free b128 reads), register prefetch.  wu layout: [4 positions][Cout][3 ky][Cin].
 // ------------------------------------------------------------------------------------------------
 constexpr int kWK = 16;        // channels per chunk
 constexpr int kWLd = kWK + 4;  // LDS row stride (floats)
 
+template <int TB>  // tiles per workgroup: 256 (wave tile 64 x 32 x 4 positions) or 128 (32 x 32 x 4) for smaller grids
 __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
-  constexpr int TB = 128, BN = 64;
-  __shared__ __align__(16) float Vs[2][4][TB][kWLd];
+  constexpr int BN = 64;
+  __shared__ __align__(16) float Ds[2][2][TB + 2][kWLd];  // raw pixels [buf][x parity][slot = tile + 1]; lane stride 20 floats
   __shared__ __align__(16) float Us[2][4][BN][kWLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  constexpr int MI = TB / 128;
+  const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * 32;
   const int lr = lane & 31, lh = lane >> 5;
   const int Wt = a.W / 2;                                   // tiles per row
   const int64_t Mt = (int64_t)a.N * a.H * Wt;               // tiles in total
@@ -182,33 +186,46 @@ __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
   const int cpt = a.Cin / kWK;
   const int nchunks = 3 * cpt;
 
-  // A staging: thread -> (tile = tid >> 2, channel quad = tid & 3)
-  const int ta = tid >> 2, qa = (tid & 3) * 4;
-  const int64_t tg = t0 + ta;
-  const bool tvalid = tg < Mt;
-  int pn = 0, py = 0, px = 0;
-  if (tvalid) {
-    pn = (int)(tg / ((int64_t)a.H * Wt));
-    const int rem = (int)(tg % ((int64_t)a.H * Wt));
-    py = rem / Wt;
-    px = (rem % Wt) * 2;
+  // A staging: (TB + 2) * 2 pixel slots x 4 channel quads = 2064 float4 items; thread -> items tid + 512 e (e < 4), and
+  // the first 16 threads one more.  Pixel coordinates of every item are fixed over the K loop.
+  constexpr int NI = (TB + 2) * 8 / 512 + 1;
+  int it_y[NI], it_slot[NI], it_q[NI];
+  int64_t it_base[NI];  // ((n * H) * W + x) * Cin + 4 q ; row term added per chunk
+  bool it_ok[NI];
+#pragma unroll
+  for (int e = 0; e < NI; ++e) {
+    const int item = tid + 512 * e;
+    const bool has = e < NI - 1 || tid < 16;
+    const int ps = item >> 2;  // pixel slot 0 .. 2*(TB+2)-1
+    it_q[e] = (item & 3) * 4;
+    it_slot[e] = ps;
+    const int64_t tg = t0 + (ps >> 1) - 1;
+    it_ok[e] = has && tg >= 0 && tg < Mt;
+    it_y[e] = 0;
+    it_base[e] = 0;
+    if (it_ok[e]) {
+      const int n = (int)(tg / ((int64_t)a.H * Wt));
+      const int rem = (int)(tg % ((int64_t)a.H * Wt));
+      it_y[e] = rem / Wt;
+      const int x = (rem % Wt) * 2 + (ps & 1);
+      it_base[e] = (((int64_t)n * a.H) * a.W + x) * a.Cin + it_q[e];
+    }
+    if (!has) it_slot[e] = -1;
   }
-  // B staging: 4 positions x 64 couts x 16 k = 1024 float4; thread -> two float4: (pos, co, quad)
+  // B staging: 4 positions x 64 couts x 16 k = 1024 float4; thread -> two float4
   const int ub_pos[2] = {tid >> 8, 2 + (tid >> 8)};
   const int ub_co = (tid >> 2) & 63, ub_q = (tid & 3) * 4;
   const bool uvalid = n0 + ub_co < a.Cout;
 
-  float4 rd[4], ru[2];
+  float4 rd[NI], ru[2];
   auto load_chunk = [&](int c) {
     const int ky = c / cpt, c0 = (c % cpt) * kWK;
-    const int hy = py + ky - 1;
-    const bool rowok = tvalid && hy >= 0 && hy < a.H;
-    const float* rowp = a.in + (((int64_t)pn * a.H + (rowok ? hy : 0)) * a.W) * a.Cin + c0 + qa;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int wx = px - 1 + e;
-      const bool ok = rowok && wx >= 0 && wx < a.W;
-      rd[e] = ok ? *reinterpret_cast<const float4*>(rowp + (int64_t)wx * a.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = 0; e < NI; ++e) {
+      const int hy = it_y[e] + ky - 1;
+      const bool ok = it_ok[e] && hy >= 0 && hy < a.H;
+      rd[e] = ok ? *reinterpret_cast<const float4*>(a.in + it_base[e] + (int64_t)hy * a.W * a.Cin + c0)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -217,20 +234,30 @@ __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
     }
   };
   auto store_chunk = [&](int buf) {
-    const float4 d0 = rd[0], d1 = rd[1], d2 = rd[2], d3 = rd[3];
-    *reinterpret_cast<float4*>(&Vs[buf][0][ta][qa]) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-    *reinterpret_cast<float4*>(&Vs[buf][1][ta][qa]) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-    *reinterpret_cast<float4*>(&Vs[buf][2][ta][qa]) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-    *reinterpret_cast<float4*>(&Vs[buf][3][ta][qa]) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+#pragma unroll
+    for (int e = 0; e < NI; ++e)
+      if (it_slot[e] >= 0) *reinterpret_cast<float4*>(&Ds[buf][it_slot[e] & 1][it_slot[e] >> 1][it_q[e]]) = rd[e];
     *reinterpret_cast<float4*>(&Us[buf][ub_pos[0]][ub_co][ub_q]) = ru[0];
     *reinterpret_cast<float4*>(&Us[buf][ub_pos[1]][ub_co][ub_q]) = ru[1];
   };
 
-  float16_t acc[4];
+  // per-lane tile rows of the two 32-tile halves of the wave tile: row-boundary flags (zero padding in x)
+  float mfirst[MI], mlast[MI];  // 0 where the tile touches the left / right image border (zero padding in x)
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int64_t tg = t0 + wm + i * 32 + lr;
+    const int xt = (int)(tg % Wt);
+    mfirst[i] = xt == 0 ? 0.f : 1.f;
+    mlast[i] = xt == Wt - 1 ? 0.f : 1.f;
+  }
+
+  float16_t acc[4][MI];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
 
   load_chunk(0);
   store_chunk(0);
@@ -240,19 +267,33 @@ __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
     if (c + 1 < nchunks) load_chunk(c + 1);
 #pragma unroll
     for (int g = 0; g < kWK / 8; ++g) {
-      float4 af[4], bf[4];
+      const int ko = g * 8 + 4 * lh;
+      float4 v[4][MI], bf[4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        af[p] = *reinterpret_cast<const float4*>(&Vs[buf][p][wm + lr][g * 8 + 4 * lh]);
-        bf[p] = *reinterpret_cast<const float4*>(&Us[buf][p][wn + lr][g * 8 + 4 * lh]);
+      for (int p = 0; p < 4; ++p) bf[p] = *reinterpret_cast<const float4*>(&Us[buf][p][wn + lr][ko]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int sl = wm + i * 32 + lr + 1;
+        const float4 d1 = *reinterpret_cast<const float4*>(&Ds[buf][0][sl][ko]);
+        const float4 d2 = *reinterpret_cast<const float4*>(&Ds[buf][1][sl][ko]);
+        const float4 d0 = *reinterpret_cast<const float4*>(&Ds[buf][1][sl - 1][ko]);
+        const float4 d3 = *reinterpret_cast<const float4*>(&Ds[buf][0][sl + 1][ko]);
+        const float f0 = mfirst[i], f3 = mlast[i];
+        v[0][i] = make_float4(fmaf(d0.x, f0, -d2.x), fmaf(d0.y, f0, -d2.y), fmaf(d0.z, f0, -d2.z), fmaf(d0.w, f0, -d2.w));
+        v[1][i] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+        v[2][i] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+        v[3][i] = make_float4(fmaf(-d3.x, f3, d1.x), fmaf(-d3.y, f3, d1.y), fmaf(-d3.z, f3, d1.z), fmaf(-d3.w, f3, d1.w));
       }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const float av = s4 == 0 ? af[p].x : s4 == 1 ? af[p].y : s4 == 2 ? af[p].z : af[p].w;
           const float bv = s4 == 0 ? bf[p].x : s4 == 1 ? bf[p].y : s4 == 2 ? bf[p].z : bf[p].w;
-          acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const float av = s4 == 0 ? v[p][i].x : s4 == 1 ? v[p][i].y : s4 == 2 ? v[p][i].z : v[p][i].w;
+            acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p][i], 0, 0, 0);
+          }
         }
       }
     }
@@ -265,20 +306,23 @@ __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
   if (co >= a.Cout) return;
   const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t t = t0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (t >= Mt) continue;
-    const int n = (int)(t / ((int64_t)a.H * Wt));
-    const int rem = (int)(t % ((int64_t)a.H * Wt));
-    const int64_t pix = ((int64_t)n * a.H + rem / Wt) * a.W + (rem % Wt) * 2;
-    float y0 = acc[0][r] + acc[1][r] + acc[2][r] + bv;
-    float y1 = acc[1][r] - acc[2][r] - acc[3][r] + bv;
-    if (a.res != nullptr) {
-      y0 += a.res[pix * a.Cout + co];
-      y1 += a.res[(pix + 1) * a.Cout + co];
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t t = t0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (t >= Mt) continue;
+      const int n = (int)(t / ((int64_t)a.H * Wt));
+      const int rem = (int)(t % ((int64_t)a.H * Wt));
+      const int64_t pix = ((int64_t)n * a.H + rem / Wt) * a.W + (rem % Wt) * 2;
+      float y0 = acc[0][i][r] + acc[1][i][r] + acc[2][i][r] + bv;
+      float y1 = acc[1][i][r] - acc[2][i][r] - acc[3][i][r] + bv;
+      if (a.res != nullptr) {
+        y0 += a.res[pix * a.Cout + co];
+        y1 += a.res[(pix + 1) * a.Cout + co];
+      }
+      a.out[pix * a.Cout + co] = y0;
+      a.out[(pix + 1) * a.Cout + co] = y1;
     }
-    a.out[pix * a.Cout + co] = y0;
-    a.out[(pix + 1) * a.Cout + co] = y1;
   }
 }
 
@@ -759,8 +803,11 @@ int fh_conv3x3_wino_nhwc(const float* in, const float* wu, const float* bias, co
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = 3, a.KW = 3, a.pad = 1, a.stride = 1;
   a.Ho = H, a.Wo = W, a.ksplit = 1, a.ws = nullptr;
   const int64_t Mt = (int64_t)N * H * (W / 2);
-  hipLaunchKernelGGL(k_conv_wino, dim3((unsigned)((Mt + 127) / 128), (Cout + 63) / 64, 1), dim3(512), 0,
-                     (hipStream_t)stream, a);
+  const int nb = (Cout + 63) / 64;
+  if (((Mt + 255) / 256) * nb >= 224)  // a full wave of 256-tile workgroups over the 256 CUs, else the finer tiling
+    hipLaunchKernelGGL(k_conv_wino<256>, dim3((unsigned)((Mt + 255) / 256), nb, 1), dim3(512), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_conv_wino<128>, dim3((unsigned)((Mt + 127) / 128), nb, 1), dim3(512), 0, (hipStream_t)stream, a);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -34,9 +34,15 @@ def _wino(w):
 
 
 def _use_wino(N, H, W, K, rows_out):
-    """Measured on MI355X: the fused F(2,3) kernel wins 1.10-1.13x once K = Cin >= 256 and the tile grid fills the chip;
-    below that the direct kernel (or split-K) is faster."""
-    return W % 2 == 0 and K % 16 == 0 and K >= 256 and N * H * (W // 2) >= 16384 and rows_out >= 64
+    """Measured on MI355X (scratch/bench_wino.py): the fused F(2,3) kernel is 1.23-1.25x the direct kernel when a full
+    wave of 256-tile workgroups covers the chip (1.11x at K = Cin = 128), ~1.14x with the 128-tile variant at K >= 256;
+    smaller grids stay on the direct kernel (or split-K).  Mirrors the variant choice of fh_conv3x3_wino_nhwc."""
+    if W % 2 or K % 16 or K < 128:
+        return False
+    mt, nb = N * H * (W // 2), -(-rows_out // 64)
+    if -(-mt // 256) * nb >= 224:
+        return True
+    return K >= 256 and -(-mt // 128) * nb >= 256
 
 
 class _Conv:

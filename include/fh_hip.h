@@ -213,6 +213,20 @@ int fh_layout_nchw_nhwc(const float* in, float* out, int N, int C, int64_t P, in
 /* out = a + b over n floats (n % 4 == 0) */
 int fh_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* ---- dense-matrix covariance path (float64, batched [bs][d][d] row-major) ------------------------------------------
+ * Device side of the reference's dense update rules update_covariance / update_bfgs
+ * (conditioning_utils/online_update_bfgs.py:377-463): the (bs,d,d) @ (bs,d,1) products and the outer-product updates.
+ *   fh_dense_matvec: y[b] = alpha * op(A[b]) x[b] + beta * y[b]   (trans = 0: A, 1: A^T; x, y [bs][d]).
+ *                    trans = 1 needs `scratch` of fh_dense_matvec_scratch_doubles(bs, d) doubles (fixed-order reduction).
+ *   fh_dense_rank2:  out[b] = scale * (A[b] + a1[b] u1[b] v1[b]^T + a2[b] u2[b] v2[b]^T) + shift * I;
+ *                    a1, a2 are DEVICE arrays [bs]; u?/v? [bs][d]; a null u? drops that term; out may alias A. */
+int64_t fh_dense_matvec_scratch_doubles(int bs, int64_t d);
+int fh_dense_matvec(const double* A, const double* x, double* y, double* scratch, int bs, int64_t d, int trans,
+                    double alpha, double beta, void* stream);
+int fh_dense_rank2(const double* A, double* out, int bs, int64_t d, const double* u1, const double* v1,
+                   const double* a1, const double* u2, const double* v2, const double* a2, double scale, double shift,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

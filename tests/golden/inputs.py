@@ -58,3 +58,47 @@ def smooth_image(size, seed):
     return torch.from_numpy(img[None].astype(np.float32))
 
 
+
+
+def dense_case(seed, bs, d, n_steps=3):
+    """Seeded inputs for the dense-helper chain (online_update_bfgs.py:377-463): a Gaussian prior N(0, S) with
+    S = Q diag(lam) Q^T, Q = I - 2 w w^T, gives the four matrices at sigma_0 in closed form (no inverse needed);
+    the chain then alternates update_covariance and update_bfgs as `dense_chain` below prescribes."""
+    g = rng(seed)
+    sig = [5.0, 3.0, 2.0, 1.2, 0.8, 0.5][:n_steps + 1]
+    w = torch.randn(bs, d, generator=g, dtype=F64)
+    w = w / w.norm(dim=-1, keepdim=True)
+    lam = 0.2 + 1.8 * torch.rand(bs, d, generator=g, dtype=F64)
+
+    def qdq(diag):  # (I - 2ww^T) D (I - 2ww^T) in O(d^2)
+        dw = diag * w
+        wdw = (w * dw).sum(-1)
+        return (torch.diag_embed(diag) - 2 * w[:, :, None] * dw[:, None, :] - 2 * dw[:, :, None] * w[:, None, :]
+                + 4 * wdw[:, None, None] * w[:, :, None] * w[:, None, :])
+
+    s0 = sig[0]
+    mats = dict(C=qdq(1 / (1 / lam + s0 ** -2)), Ci=qdq(1 / lam + s0 ** -2), H=qdq(-1 / (lam + s0 ** 2)),
+                Hi=qdq(-(lam + s0 ** 2)))
+    x = torch.randn(bs, d, generator=g, dtype=F64) * s0
+    score = torch.randn(bs, d, generator=g, dtype=F64) / s0
+    e1 = [torch.randn(bs, d, generator=g, dtype=F64) for _ in range(n_steps)]
+    e2 = [torch.randn(bs, d, generator=g, dtype=F64) for _ in range(n_steps)]
+    return dict(sig=sig, x=x, score=score, e1=e1, e2=e2, **mats)
+
+
+def dense_chain(case, time_update, space_update, to=lambda t: t):
+    """Drive `time_update` (signature of update_covariance) and `space_update` (update_bfgs) through the scripted
+    chain; `to` moves inputs to the implementation's device.  Yields the state after every update."""
+    sig = case["sig"]
+    C, Ci, H, Hi = (to(case[k].clone()) for k in ("C", "Ci", "H", "Hi"))
+    x, score = to(case["x"]), to(case["score"])
+    mean = x + sig[0] ** 2 * score
+    sched = lambda t: t  # noqa: E731  (noise level = time)
+    for i in range(len(case["e1"])):
+        C, Ci, H, Hi, score, mean = time_update(x, C, Ci, H, Hi, score, mean, sched, sig[i], sig[i + 1])
+        yield ("time", i, C, Ci, H, Hi, score, mean)
+        xn = x + 0.3 * to(case["e1"][i])
+        m1 = mean + 0.4 * (xn - x) + 0.02 * to(case["e2"][i])
+        C, Ci, H, Hi = space_update(C, Ci, mean, m1, sched, sig[i + 1], x, xn - x)
+        yield ("space", i, C, Ci, H, Hi, None, None)
+        x, score = xn, (m1 - xn) / sig[i + 1] ** 2

@@ -74,7 +74,7 @@ from training.openai_util import create_model  # noqa: E402
 
 from oracle.unet_oracle import UNetConfig, seeded_state  # noqa: E402  (weights recipe + config only)
 sys.path.insert(0, HERE)
-from inputs import SMALL_A, SMALL_B, randn, rng, script as _script, smooth_image  # noqa: E402
+from inputs import SMALL_A, SMALL_B, dense_case, dense_chain, randn, rng, script as _script, smooth_image  # noqa: E402
 
 F64 = torch.float64
 
@@ -207,6 +207,34 @@ def gold_cov():
                 for nm, m in zip(("C", "Ci", "H", "Hi"), dm):
                     out[pre + nm] = m
     save("covariance", **out)
+
+
+# ------------------------------------------------------------------ 3b. dense helpers (analytic cross-check, config 3)
+DENSE_CASES = [("d5", 11, 2, 5), ("d15", 12, 2, 15), ("d256", 13, 2, 256)]
+DENSE_ROWS = 64  # d = 256: every 64th row of each matrix is stored, plus matrix x probe products
+
+
+def gold_dense():
+    """update_covariance / update_bfgs (online_update_bfgs.py:377-463) driven through inputs.dense_chain."""
+    out = {}
+    torch.set_default_dtype(torch.float64)  # the helpers build torch.eye(d) in the default dtype
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)  # this torch build's threaded batched LU (MKL DLASWP) misbehaves for small batched inverses
+    try:
+        for tag, seed, bs, d in DENSE_CASES:
+            case = dense_case(seed, bs, d)
+            probe = randn((bs, d), 3000 + seed)
+            for what, i, C, Ci, H, Hi, score, mean in dense_chain(case, ref_cov.update_covariance, ref_cov.update_bfgs):
+                pre = f"{tag}__{what}{i}_"
+                for nm, m in zip(("C", "Ci", "H", "Hi"), (C, Ci, H, Hi)):
+                    out[pre + nm] = m if d <= 15 else m[:, ::DENSE_ROWS]
+                    out[pre + nm + "_probe"] = (m @ probe[..., None])[..., 0]
+                if score is not None:
+                    out[pre + "score"], out[pre + "mean"] = score, mean
+    finally:
+        torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(nthreads)
+    save("dense_helpers", **out)
 
 
 # ------------------------------------------------------------------ 4. operators (a13)
@@ -407,4 +435,4 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     for w in which:
         {"sigma": gold_sigma, "unet": gold_unet, "cov": gold_cov, "ops": gold_ops, "solver": gold_solver,
-         "traj": gold_traj}[w]()
+         "traj": gold_traj, "dense": gold_dense}[w]()

@@ -251,3 +251,47 @@ def test_trajectory(gold, tag, tmp_path):
         assert [int(t["branch"] == "cov") for t in tr] == list(g[p + "branch_cov"])
         assert [t["niter"] for t in tr] == list(g[p + "niter"])
         assert maxabs(x, g[p + "x_final"]) < 1e-3
+
+
+# ---------------------------------------------------------------- dense helpers (analytic cross-check; config 3)
+DENSE_CASES = [("d5", 11, 2, 5), ("d15", 12, 2, 15), ("d256", 13, 2, 256)]
+DENSE_ROWS = 64
+
+
+def oracle_dense_updates():
+    """Batched wrappers (loop over bs) around the oracle's single-matrix dense rules, with the reference signatures."""
+    def time_update(x, C, Ci, H, Hi, score, mean, sched, t, tn):
+        outs = [fo.dense_time_update(x[b], C[b], Ci[b], H[b], Hi[b], score[b], sched(t), sched(tn))
+                for b in range(x.shape[0])]
+        return tuple(torch.stack([o[k] for o in outs]) for k in range(6))
+
+    def space_update(C, Ci, m0, m1, sched, t, x, dx):
+        outs = [fo.dense_space_update(C[b], Ci[b], m0[b], m1[b], sched(t), dx[b]) for b in range(dx.shape[0])]
+        return tuple(torch.stack([o[k] for o in outs]) for k in range(4))
+
+    return time_update, space_update
+
+
+def check_dense_chain(gold, chain_states, tag, d, probe, tol):
+    g = gold("dense_helpers")
+    for what, i, C, Ci, H, Hi, score, mean in chain_states:
+        pre = f"{tag}__{what}{i}_"
+        for nm, m in zip(("C", "Ci", "H", "Hi"), (C, Ci, H, Hi)):
+            ref = T(g[pre + nm])
+            got = T(m).cpu() if d <= 15 else T(m).cpu()[:, ::DENSE_ROWS]
+            scale = max(1.0, float(ref.abs().max()))
+            assert float((got - ref).abs().max()) < tol * scale, (tag, what, i, nm)
+            refp = T(g[pre + nm + "_probe"])
+            gotp = (T(m).cpu() @ probe[..., None])[..., 0]
+            assert float((gotp - refp).abs().max()) < tol * max(1.0, float(refp.abs().max())), (tag, what, i, nm)
+        if score is not None:
+            assert maxabs(score.cpu(), g[pre + "score"]) < tol * max(1.0, float(np.abs(g[pre + "score"]).max()))
+            assert maxabs(mean.cpu(), g[pre + "mean"]) < tol * max(1.0, float(np.abs(g[pre + "mean"]).max()))
+
+
+@pytest.mark.parametrize("tag,seed,bs,d", DENSE_CASES)
+def test_dense_helpers_vs_reference(gold, tag, seed, bs, d):
+    """Oracle dense rules against update_covariance / update_bfgs outputs captured from the reference."""
+    case = inputs.dense_case(seed, bs, d)
+    tu, su = oracle_dense_updates()
+    check_dense_chain(gold, inputs.dense_chain(case, tu, su), tag, d, inputs.randn((bs, d), 3000 + seed), 1e-9)
