@@ -34,6 +34,18 @@ struct ConvArgs {
   float* ws;
 };
 
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own L2.
+// Remap so that one XCD walks a contiguous range of pixel tiles, visiting all Cout tiles of a pixel tile back to back:
+// neighbouring pixel tiles (which share the 3x3 halo rows) and the weight panel then hit in that XCD's L2.
+__device__ __forceinline__ void xcd_tile(int& tile_m, int& tile_n) {
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned total = gx * gy;
+  unsigned lin = blockIdx.y * gx + blockIdx.x;
+  if ((total & 7u) == 0) lin = (lin & 7u) * (total >> 3) + (lin >> 3);
+  tile_n = (int)(lin % gy);
+  tile_m = (int)(lin / gy);
+}
+
 template <int MI, int NI>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   constexpr int BM = 2 * MI * 32, BN = 2 * NI * 32;
@@ -132,6 +144,215 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn + j * 32 + lr;
+    if (co >= a.Cout) continue;
+    const float bv = (a.bias != nullptr && a.ksplit == 1) ? a.bias[co] : 0.f;
+    float* dst = a.ksplit == 1 ? a.out : a.ws + (int64_t)blockIdx.z * M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (a.res != nullptr && a.ksplit == 1) v += a.res[row * a.Cout + co];
+          dst[row * a.Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 convolution on the bf16 matrix cores by exact operand splitting ("bf16x6").
+//   Every fp32 value is the exact sum of three bf16 numbers, x = h + m + l (h = rn(x), m = rn(x - h), l = rn(x - h - m);
+//   three signed 8-bit significands cover the 24-bit fp32 significand).  The product of two split operands has nine
+//   terms, each exact in fp32; the six largest (hh', hm', mh', hl', lh', mm') are accumulated in fp32 by
+//   v_mfma_f32_32x32x16_bf16 and the three dropped ones are below 2^-24 |x y| - the size of one fp32 rounding - so the
+//   result carries the error of an fp32 dot product (tests: error against float64 on par with the fp32-MFMA kernel).
+//   Six bf16 MFMAs (32 cycles each, K = 16) replace eight fp32 MFMAs (64 cycles each, K = 2): 2.67x the fp32 matrix
+//   peak.  gfx950 has no xf32 path, so this is the only way past 157 TFLOP/s at fp32 accuracy.
+// Same implicit-GEMM tiling as k_conv_igemm (4 waves, (2*MI*32) x (2*NI*32) tile, K chunks of 32 channels).  The
+// activation operand is split while it is staged (global fp32 -> registers -> 3 bf16 planes in LDS; ~6 VALU per
+// element, hidden under the MFMAs); the weights are split once on the host, wx [3 planes][taps][Cin/32][Cout][32]
+// bf16, so that the weight tile of a K chunk is one contiguous run of 64-byte rows.
+// LDS rows are 32 bf16 + 8 pad = 80 B, so the 16-byte fragment reads (8 consecutive k per lane) are conflict-free;
+// one buffer (61 KB for 128 x 128) keeps two workgroups per CU, which hide each other's staging barriers.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int kXLd = kBK + 8;  // bf16 row stride (80 B)
+
+struct ConvArgsX {
+  const float* in;
+  const __bf16* wx;   // [3 planes][taps][Cin/32][Cout][32]
+  const float* bias;
+  const float* res;
+  float* out;
+  int N, H, W, Cin, Cout, KH, KW, pad, stride, Ho, Wo;
+  int ksplit;
+  float* ws;
+};
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  float r = x - (float)h;
+  m = (__bf16)r;
+  r -= (float)m;
+  l = (__bf16)r;
+}
+
+template <int MI, int NI, int WM, int WN, int MINW>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
+__global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
+  constexpr int T = 64 * WM * WN;
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr int IA = BM * 8 / T;      // float4 items per thread per chunk (A tile = BM rows x 8 float4)
+  constexpr int IB = 3 * BN * 4 / T;  // 16-byte items per thread per chunk (B tile = 3 planes x BN rows x 4 parts)
+  static_assert(BM * 8 % T == 0 && 3 * BN * 4 % T == 0, "tile / thread-count mismatch");
+  __shared__ __align__(16) __bf16 As[3][BM][kXLd];
+  __shared__ __align__(16) __bf16 Bs[3][BN][kXLd];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int taps = a.KH * a.KW;
+  const int cpt = a.Cin / kBK;
+  const int nchunks_all = taps * cpt;
+  const int c_begin = (int)((int64_t)nchunks_all * blockIdx.z / a.ksplit);
+  const int c_end = (int)((int64_t)nchunks_all * (blockIdx.z + 1) / a.ksplit);
+
+  // Staging maps: consecutive lanes take consecutive 16-byte pieces, so a wave-load covers whole 128-byte lines
+  // (8 lanes per pixel row of 32 floats) instead of 32 partial lines - the vector-memory path, not the MFMA, bounds
+  // this kernel.  Item e of a thread is element e * 256 + tid of the tile.
+  int a_row[IA], a_n[IA], a_ho[IA], a_wo[IA];
+  bool a_ok[IA];
+  const int a_c4 = (tid & 7) * 4;
+#pragma unroll
+  for (int e = 0; e < IA; ++e) {
+    a_row[e] = (e * T + tid) >> 3;
+    const int64_t pm = m0 + a_row[e];
+    a_ok[e] = pm < M;
+    a_n[e] = a_ho[e] = a_wo[e] = 0;
+    if (a_ok[e]) {
+      a_n[e] = (int)(pm / ((int64_t)a.Ho * a.Wo));
+      const int rem = (int)(pm % ((int64_t)a.Ho * a.Wo));
+      a_ho[e] = rem / a.Wo;
+      a_wo[e] = rem % a.Wo;
+    }
+  }
+  // weights: wx [3][taps][Cin/32][Cout][32] - the B tile of one plane is BN contiguous 64-byte rows
+  const int64_t wplane = (int64_t)taps * cpt * a.Cout * kBK;
+  int b_pl[IB], b_row[IB];
+  bool b_ok[IB];
+  const int b_part = (tid & 3) * 8;
+#pragma unroll
+  for (int e = 0; e < IB; ++e) {
+    const int idx = e * T + tid;
+    b_pl[e] = idx / (BN * 4);
+    b_row[e] = (idx % (BN * 4)) >> 2;
+    b_ok[e] = n0 + b_row[e] < a.Cout;
+  }
+
+  float4 ra_reg[IA];
+  bf16x8_t rb_reg[IB];
+
+  auto load_chunk = [&](int c) {
+    const int cc = c / taps, tap = c % taps;  // channel chunk outer, taps inner: the 9 taps re-read the same lines while hot in L2
+    const int ky = tap / a.KW, kx = tap % a.KW;
+#pragma unroll
+    for (int e = 0; e < IA; ++e) {
+      const int hi = a_ho[e] * a.stride + ky - a.pad, wi = a_wo[e] * a.stride + kx - a.pad;
+      const bool ok = a_ok[e] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      const float* src = a.in + (((int64_t)a_n[e] * a.H + (ok ? hi : 0)) * a.W + (ok ? wi : 0)) * a.Cin + cc * kBK + a_c4;
+      ra_reg[e] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const __bf16* wbase = a.wx + ((int64_t)tap * cpt + cc) * a.Cout * kBK;
+#pragma unroll
+    for (int e = 0; e < IB; ++e) {
+      bf16x8_t z;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) z[q] = (__bf16)0.f;
+      const __bf16* src = wbase + b_pl[e] * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
+      rb_reg[e] = b_ok[e] ? *reinterpret_cast<const bf16x8_t*>(src) : z;
+    }
+  };
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int e = 0; e < IA; ++e) {
+      bf16x4_t h4, m4, l4;
+      const float4 v = ra_reg[e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+        __bf16 h, m, l;
+        split3(x, h, m, l);
+        h4[q] = h, m4[q] = m, l4[q] = l;
+      }
+      *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
+      *reinterpret_cast<bf16x4_t*>(&As[1][a_row[e]][a_c4]) = m4;
+      *reinterpret_cast<bf16x4_t*>(&As[2][a_row[e]][a_c4]) = l4;
+    }
+#pragma unroll
+    for (int e = 0; e < IB; ++e) *reinterpret_cast<bf16x8_t*>(&Bs[b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
+  };
+
+  float16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&]() {
+#pragma unroll
+  for (int ks = 0; ks < kBK / 16; ++ks) {
+    const int ko = ks * 16 + 8 * lh;
+    bf16x8_t af[3][MI], bfr[3][NI];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][wm + i * 32 + lr][ko]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[p][wn + j * 32 + lr][ko]);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        float16_t t = acc[i][j];
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], t, 0, 0, 0);  // l h'
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], t, 0, 0, 0);  // h l'
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], t, 0, 0, 0);  // m m'
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], t, 0, 0, 0);  // m h'
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], t, 0, 0, 0);  // h m'
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);  // h h'
+        acc[i][j] = t;
+      }
+  }
+  };
+
+  // registers prefetch chunk c + 1 while chunk c is multiplied; one LDS buffer (two workgroups per CU overlap instead)
+  load_chunk(c_begin);
+  store_chunk();
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    if (c + 1 < c_end) load_chunk(c + 1);
+    compute();
+    __syncthreads();
+    if (c + 1 < c_end) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int co = n0 + wn + j * 32 + lr;
@@ -784,6 +1005,39 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
     hipLaunchKernelGGL((k_conv_igemm<1, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((k_conv_igemm<1, 1>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+  }
+  if (ksplit > 1) {
+    const int64_t total = M * Cout;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, bias, res, out, total,
+                       Cout, ksplit);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                      int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                      void* stream) {
+  if (!in || !wx || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
+    return FH_EINVAL;
+  if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
+  ConvArgsX a;
+  a.in = in, a.wx = (const __bf16*)wx, a.bias = bias, a.res = res, a.out = out;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
+  a.Ho = (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  a.ksplit = ksplit, a.ws = ws;
+  const int64_t M = (int64_t)N * a.Ho * a.Wo;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned Z = (unsigned)ksplit;
+  // 128 x 128 tiles run as 8 waves (2 x 4, wave tile 64 x 32: 102 VGPRs, 4 waves per SIMD over two workgroups per CU)
+  const int64_t b128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+  if (ksplit == 1 && Cout > 64 && b128 >= 384) {
+    hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+  } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
+    hipLaunchKernelGGL((k_conv_x6<1, 2, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_conv_x6<1, 1, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
   }
   if (ksplit > 1) {
     const int64_t total = M * Cout;

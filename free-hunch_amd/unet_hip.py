@@ -13,6 +13,7 @@ of 32 where they are the GEMM K dimension).
 from __future__ import annotations
 
 import math
+import os
 import threading
 
 import torch
@@ -45,6 +46,28 @@ def _use_wino(N, H, W, K, rows_out):
     return K >= 256 and -(-mt // 128) * nb >= 256
 
 
+def _split3(w):
+    """fp32 [rows][taps][K] -> bf16 [3 planes][taps][K/32][rows][32] with w == p0 + p1 + p2 exactly (fh_conv2d_x6_nhwc)."""
+    h = w.to(torch.bfloat16)
+    r = w - h.float()
+    m = r.to(torch.bfloat16)
+    lo = (r - m.float()).to(torch.bfloat16)
+    rows, taps, k = w.shape
+    return torch.stack([h, m, lo]).reshape(3, rows, taps, k // _K, _K).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def _use_x6(N, H, W, rows_out):
+    """Measured on MI355X (scratch/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (and 1.05-1.1x
+    the Winograd one) once its 64/128-row tiles fill the chip; on the small grids (<= 16 x 16 at batch 8) the fp32
+    kernel with split-K is ~10 % faster."""
+    return rows_out > 64 and -(-(N * H * W) // 64) * -(-rows_out // 128) >= 256
+
+
+# conv arithmetic: "x6" = exact-split bf16 MFMA (fp32 accuracy, default), "wino" = fp32 MFMA + F(2,3), "f32" = fp32 MFMA only
+CONV_MODE = os.environ.get("FH_CONV_MODE", "x6")
+assert CONV_MODE in ("x6", "wino", "f32"), CONV_MODE
+
+
 class _Conv:
     def __init__(self, w, b):
         co, ci = w.shape[0], w.shape[1]
@@ -58,10 +81,12 @@ class _Conv:
         wd[:, :, :co] = w4.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, kh * kw, co)
         self.wf, self.wd, self.b = wf.contiguous(), wd.contiguous(), b.float().contiguous()
         # F(2,3) Winograd copies along kx, [4][rows][3 ky][K]: used for the large 3x3 layers (fh_conv3x3_wino_nhwc)
-        self.wu_f = self.wu_d = None
-        if kh == 3 and kw == 3:
+        self.wu_f = self.wu_d = self.wx_f = self.wx_d = None
+        if kh == 3 and kw == 3 and CONV_MODE == "wino":
             self.wu_f = _wino(wf.reshape(co, 3, 3, self.ci_p))
             self.wu_d = _wino(wd.reshape(ci, 3, 3, self.co_p))
+        if CONV_MODE == "x6":  # exact bf16 split of both copies (6 bytes per weight)
+            self.wx_f, self.wx_d = _split3(self.wf), _split3(self.wd)
 
 
 class HipOps:
@@ -90,6 +115,11 @@ class HipOps:
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      Ci, c.co, _lib.stream()), "fh_conv3x3_wino_nhwc")
             return out
+        if c.wx_f is not None and _use_x6(N, H, W, c.co):
+            _lib.check(self.lib.fh_conv2d_x6_nhwc(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
+                                                  None if res is None else res.data_ptr(), out.data_ptr(), None, 1, N, H,
+                                                  W, Ci, c.co, c.kh, c.kw, pad, 1, _lib.stream()), "fh_conv2d_x6_nhwc")
+            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
@@ -110,6 +140,12 @@ class HipOps:
             _lib.check(self.lib.fh_conv3x3_wino_nhwc(g.data_ptr(), c.wu_d.data_ptr(), None,
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      c.co_p, c.ci, _lib.stream()), "fh_conv3x3_wino_nhwc(dgrad)")
+            return out
+        if c.wx_d is not None and _use_x6(N, H, W, c.ci):
+            _lib.check(self.lib.fh_conv2d_x6_nhwc(g.data_ptr(), c.wx_d.data_ptr(), None,
+                                                  None if res is None else res.data_ptr(), out.data_ptr(), None, 1, N, H,
+                                                  W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()),
+                       "fh_conv2d_x6_nhwc(dgrad)")
             return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None

@@ -171,6 +171,14 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
  * sums go to ws [ksplit][N*Ho*Wo][Cout] (caller-owned) and a second kernel adds them in a fixed order (+ bias, res). */
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 
+/* Same convolution as fh_conv2d_nhwc at fp32 accuracy on the bf16 matrix cores: operands are split exactly into three
+ * bf16 planes (x = h + m + l) and the six leading cross products are accumulated in fp32 (dropped terms < 2^-24 |x y|).
+ * wx: weights split by the caller, bf16 [3 planes][KH*KW][Cin/32][Cout][32] (plane 0 = rn(w), 1 = rn(w - p0),
+ * 2 = rn(w - p0 - p1); K chunks of 32 input channels are contiguous per output channel). */
+int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                      int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                      void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution through a fused 1-D Winograd F(2,3) transform along W (W even, Cin % 16 == 0):
  * 1.5x fewer multiplies than fh_conv2d_nhwc at the same exact-fp32 MFMA.  wu is the pre-transformed weight
  * [4][Cout][3][Cin]:  wu[0] = w[.,.,ky,0], wu[1] = (w0+w1+w2)/2, wu[2] = (w0-w1+w2)/2, wu[3] = w[.,.,ky,2] over kx.

@@ -189,6 +189,64 @@ def test_conv_winograd_vs_torch(dev, shape):
     assert rel(out.permute(0, 3, 1, 2), ref) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64, 128, 128, 3, 1), (2, 16, 32, 64, 96, 3, 1), (1, 256, 256, 32, 128, 3, 1),
+                                   (1, 9, 14, 32, 6, 3, 1), (3, 8, 8, 160, 64, 3, 1), (2, 32, 32, 256, 320, 1, 1),
+                                   (1, 33, 31, 64, 130, 3, 2), (8, 64, 64, 128, 256, 3, 1)])
+def test_conv_split_bf16_vs_float64(dev, shape):
+    """fh_conv2d_x6_nhwc (exact 3-way bf16 split, six products) against float64: the error must be that of an fp32
+    dot product - checked relative to the fp32-MFMA kernel on the same data (<= 1.5x its error, and < 2e-6 of scale)."""
+    from free_hunch_amd.unet_hip import _split3
+    L, lib = _lib()
+    N, H, W, Ci, Co, k, stride = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = (torch.randn(N, Ci, H, W, generator=g) * (0.2 + 3 * torch.rand(N, Ci, H, W, generator=g))).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    pad = k // 2
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad, stride=stride)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = torch.randn(N, Co, Ho, Wo, generator=g).to(dev)
+    ref = ref + res.double()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    rn = res.permute(0, 2, 3, 1).contiguous()
+    wf = w.permute(0, 2, 3, 1).reshape(Co, k * k, Ci).contiguous()
+    wx = _split3(wf)
+    planes = wx.float().permute(0, 3, 1, 2, 4).reshape(3, Co, k * k, Ci)
+    assert torch.equal(planes.sum(0), wf) or float((planes.double().sum(0) - wf.double()).abs().max()) == 0.0
+    outs = []
+    for which in ("x6", "f32"):
+        out = torch.full((N, Ho, Wo, Co), float("nan"), device=dev)
+        if which == "x6":
+            L.check(lib.fh_conv2d_x6_nhwc(xn.data_ptr(), wx.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), None,
+                                          1, N, H, W, Ci, Co, k, k, pad, stride, L.stream()), "x6")
+        else:
+            L.check(lib.fh_conv2d_nhwc(xn.data_ptr(), wf.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), None, 1,
+                                       N, H, W, Ci, Co, k, k, pad, stride, L.stream()), "f32")
+        outs.append(float((out.permute(0, 3, 1, 2).double() - ref).abs().max()))
+    scale = float(ref.abs().max())
+    assert outs[0] < 2e-6 * scale, (outs, scale)
+    assert outs[0] <= 1.5 * outs[1] + 1e-7 * scale, (outs, scale)
+
+
+def test_conv_split_bf16_splitk(dev):
+    """K-split path of the split-bf16 kernel (small grids): partial sums through the workspace + fixed-order reduce."""
+    from free_hunch_amd.unet_hip import _split3
+    L, lib = _lib()
+    N, H, W, Ci, Co = 1, 8, 8, 512, 96
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wx = _split3(w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous())
+    out = torch.empty(N, H, W, Co, device=dev)
+    ws = torch.empty(4, N * H * W, Co, device=dev)
+    L.check(lib.fh_conv2d_x6_nhwc(xn.data_ptr(), wx.data_ptr(), b.data_ptr(), None, out.data_ptr(), ws.data_ptr(), 4, N,
+                                  H, W, Ci, Co, 3, 3, 1, 1, L.stream()), "x6 split-K")
+    assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
+
+
 def test_unet_ffhq256_hip_vs_torch_backend(dev):
     """The benchmark architecture at full size (exercises the 128x128 / Winograd / split-K kernel choices): forward and
     input-VJP of the HIP backend against the PyTorch-ROCm backend, same seeded weights."""
