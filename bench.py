@@ -114,36 +114,48 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     return torch.cat([r[0] for r in res], 0)
 
 
-def roofline_cov_apply(device, m=32, iters=200):
-    """fh_rep_apply at the headline point d = 196608, m = 32 (float64 base), events on the stream."""
+def roofline_cov_apply(device, m=32, iters=200, nimg=1):
+    """fh_rep_apply at the headline point d = 196608, m = 32 (float64 base), events on the stream.
+    nimg > 1: the batched launch the lock-step CG issues (one factor base per image, grid z = image)."""
+    import ctypes as C
     from free_hunch_amd import _lib
     S, d = 256, 3 * 256 * 256
-    ctx = _lib.Context.get(S, 3, 256)
+    ctx = _lib.Context.get(S, 3 * nimg, 256)
     g = torch.Generator(device="cpu").manual_seed(1)
-    B = torch.randn(m, d, generator=g, dtype=torch.float64).to(device)
-    D = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device)
-    r = (torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device)
-    M = torch.randn(64, 64, generator=g, dtype=torch.float64).to(device)
-    z = torch.randn(d, generator=g, dtype=torch.float64).to(device)
+    Bs = [torch.randn(m, d, generator=g, dtype=torch.float64).to(device) for _ in range(nimg)]
+    Ds = [(torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device) for _ in range(nimg)]
+    rs = [(torch.rand(d, generator=g, dtype=torch.float64) + 0.5).to(device) for _ in range(nimg)]
+    Ms = [torch.randn(64, 64, generator=g, dtype=torch.float64).to(device) for _ in range(nimg)]
+    z = torch.randn(nimg, d, generator=g, dtype=torch.float64).to(device)
     out = torch.empty_like(z)
+    if nimg == 1:
+        f = lambda: ctx.rep_apply(Ds[0], rs[0], Bs[0], Ms[0], z[0], out[0], m)
+    else:
+        per = _lib.FhBatch()
+        per.nimg = nimg
+        for i in range(nimg):
+            per.D[i], per.r[i], per.B[i], per.M[i] = Ds[i].data_ptr(), rs[i].data_ptr(), Bs[i].data_ptr(), Ms[i].data_ptr()
+        f = lambda: _lib.check(ctx.lib.fh_rep_apply_batched(ctx.h, C.byref(per), 64, z.data_ptr(), out.data_ptr(), d, m,
+                                                            _lib.stream()), "fh_rep_apply_batched")
     for _ in range(10):
-        ctx.rep_apply(D, r, B, M, z, out, m)
+        f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ctx.rep_apply(D, r, B, M, z, out, m)
+        f()
     e1.record()
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters
-    algo_bytes = 8 * d * m + 8 * d * 4  # base once + D, r, z read + out written (float64)
+    algo_bytes = nimg * (8 * d * m + 8 * d * 4)  # per image: base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
     traffic = None  # HBM-side bytes per apply from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
     pmc = os.path.join(ROOT, "profiles", "r01_cov_apply_pmc.json")
-    if m == 32 and os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = json.load(f).get("traffic_bytes_per_apply")
-    return {"bound": "hbm", "kernel": "fh_rep_apply = k_rep_dots + k_rep_coef + k_rep_apply2 (d=196608, m=32, f64)",
+    if m == 32 and nimg == 1 and os.path.exists(pmc):
+        with open(pmc) as f_:
+            traffic = json.load(f_).get("traffic_bytes_per_apply")
+    return {"bound": "hbm", "kernel": f"fh_rep_apply = k_rep_dots + k_rep_coef + k_rep_apply2 (d=196608, m={m}, f64, "
+                                      f"{nimg} image{'s' if nimg > 1 else ''} per launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
@@ -360,7 +372,10 @@ def main():
                        "net_calls_per_image": 2 * a.num_steps - 1 if a.solver == "heun" else a.num_steps,
                        "cg_iters_per_image_last_step": getattr(run_batch, "cg_iters", None)},
         }
-        line["roofline"] = roofline_cov_apply(device)
+        # headline point of SURVEY.md 8(d): d = 196608, m = 32, b = the batch the lock-step CG applies per launch
+        line["roofline"] = roofline_cov_apply(device, nimg=min(a.batch, 8), iters=100)
+        if a.batch > 1:
+            line["roofline_cov_apply_b1"] = roofline_cov_apply(device, nimg=1)
         line["roofline_unet_conv"] = roofline_conv_mfma(device)
         line["roofline_dense_cov_apply"] = roofline_dense_cov_apply(device)
         if world == 1 and not a.no_cpu_baseline:

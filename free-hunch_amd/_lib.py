@@ -41,6 +41,7 @@ _SIGS = {
     "fh_context_destroy": ([C.c_void_p], C.c_int),
     "fh_dct2d": ([C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_apply": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
+    "fh_rep_apply_batched": ([C.c_void_p, C.POINTER(FhBatch), C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_invert": ([C.c_void_p, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_int,
                        C.c_void_p], C.c_int),
     "fh_space_prep": ([C.c_void_p, c_dp, C.c_double, c_dp, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),

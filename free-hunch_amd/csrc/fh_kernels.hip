@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void k_rep_coef(fh_batch per, const double* _
 __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* __restrict__ coef,
                                                     const double* __restrict__ z, double* __restrict__ out,
                                                     int64_t d, int m, const fh_cg_state* __restrict__ states) {
-  const int img = blockIdx.z;
+  const int img = (int)gridDim.z - 1 - (int)blockIdx.z;  // images too in reverse: the last bases of pass 1 are still in the 256 MB Infinity Cache
   IMG_GUARD(states, img);
   const double* __restrict__ D = per.D[img];
   const double* __restrict__ r = per.r[img];
@@ -340,6 +340,10 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
   if (m < 0 || m > FH_MAX_COLS || (d & 1) || per.nimg < 1 || per.nimg > ctx->nimg_max) return FH_ESIZE;
   const int nb = (int)((d + kDotRows - 1) / kDotRows);
   if (nb > kPartialRows) return FH_ESIZE;
+  // All images of a batch go through pass 1, then pass 2 in reverse image (and row) order, so that the bases read last
+  // are re-read first while they are still in the 256 MB Infinity Cache.  Measured at 8 images, m = 32 (algorithmic
+  // TB/s): same order 2.75, reverse order 2.97; splitting the batch into cache-sized groups of 4 (each group both
+  // passes back to back) 2.80 - the extra dependent launches cost more than the additional hits return.
   const unsigned Z = (unsigned)per.nimg;
   if (m > 0) {
     hipLaunchKernelGGL(k_rep_dots, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
@@ -993,6 +997,16 @@ int fh_rep_apply(fh_context* ctx, const double* D, const double* r, const double
   per.nimg = 1;
   per.D[0] = D, per.r[0] = r, per.B[0] = B, per.M[0] = M;
   return rep_apply_launch(ctx, per, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
+}
+
+int fh_rep_apply_batched(fh_context* ctx, const fh_batch* per, int ldm, const double* z, double* out, int64_t d,
+                         int m, void* stream) {
+  if (!ctx || !per || !z || !out || d < 2 || per->nimg < 1 || per->nimg > FH_MAX_BATCH) return FH_EINVAL;
+  for (int i = 0; i < per->nimg; ++i) {
+    if (!per->D[i]) return FH_EINVAL;
+    if (m > 0 && (!per->r[i] || !per->B[i] || !per->M[i] || ldm < m)) return FH_EINVAL;
+  }
+  return rep_apply_launch(ctx, *per, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
 }
 
 int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,

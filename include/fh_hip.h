@@ -137,6 +137,12 @@ typedef struct fh_cg_info {
   double b_norm;
 } fh_cg_info;
 
+/* fh_rep_apply for per->nimg images in one launch (grid z = image): z, out are [nimg][d]; image i uses per->D[i], r[i],
+ * B[i], M[i] (all with m columns and leading dimension ldm).  The context must have been created with
+ * planes_max >= 3 * nimg.  This is what the batched CG runs every iteration. */
+int fh_rep_apply_batched(fh_context* ctx, const fh_batch* per, int ldm, const double* z, double* out, int64_t d, int m,
+                         void* stream);
+
 /* y -> A_mm(u) = sigma_y2*u + A C A^T u   (one application; exposed for tests) */
 int fh_amm(fh_context* ctx, const fh_problem* p, const double* u, double* out, void* stream);
 /* conditioning_utils/cg.py:118-292 with M = I, x0 = b: solves A_mm x = b, same stopping rule
