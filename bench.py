@@ -150,8 +150,8 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
     algo_bytes = nimg * (8 * d * m + 8 * d * 4)  # per image: base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
     traffic = None  # HBM-side bytes per apply from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
-    pmc = os.path.join(ROOT, "profiles", "r01_cov_apply_pmc.json")
-    if m == 32 and nimg == 1 and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "profiles", "r01_cov_apply_pmc.json" if nimg == 1 else "r01_cov_apply_b8_pmc.json")
+    if m == 32 and nimg in (1, 8) and os.path.exists(pmc):
         with open(pmc) as f_:
             traffic = json.load(f_).get("traffic_bytes_per_apply")
     return {"bound": "hbm", "kernel": f"fh_rep_apply = k_rep_dots + k_rep_coef + k_rep_apply2 (d=196608, m={m}, f64, "
