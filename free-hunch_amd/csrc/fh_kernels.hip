@@ -358,8 +358,9 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
 // ------------------------------------------------------------------------------------------------
 // Representation inverse (Woodbury) - diagonal part + weighted Gram  G = B^T diag(rx^2/Dx) B.
 //   k_invert_diag : Dx += shift, Dy = 1/Dx, ry = rx/Dx
-//   k_gram        : grid (row blocks, 64x64 tile pairs ta<=tb); each workgroup streams its rows in
-//                   chunks of 64 through LDS and keeps a 4x4 register tile per thread
+//   k_gram        : grid (row blocks, 64x64 tile pairs ta<=tb); each workgroup streams its rows in chunks of 64
+//                   through LDS; wave w accumulates the 16-row strip w of the pair on v_mfma_f64_16x16x4_f64
+//                   (one LDS read per operand per 1024 FMAs; sub-tiles beyond column m are skipped)
 //   k_gram_reduce : sums the row-block partials, writes both triangles
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, const double* __restrict__ rx,
@@ -373,14 +374,14 @@ __global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, co
   if (rx != nullptr) ry[i] = rx[i] / v;
 }
 
-constexpr int kGramRowBlocks = 128;
+constexpr int kGramRowBlocks = 512;  // 384 rows each at d = 196608: two workgroups per CU
 constexpr int kGT = 64;  // Gram tile edge and row-chunk length
 
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, const double* __restrict__ rx,
                                               const double* __restrict__ Dx, double* __restrict__ gpartial,
                                               int64_t d, int m, int ntiles) {
-  __shared__ double As[kGT][kGT + 1];  // [row][col of tile a], weighted
-  __shared__ double Bs[kGT][kGT + 1];  // [row][col of tile b]
+  __shared__ double As[kGT][kGT + 1];  // [row i][col of tile a], weighted
+  __shared__ double Bs[kGT][kGT + 1];  // [row i][col of tile b]
   // decode tile pair
   int ta = 0, tb = 0, p = blockIdx.y;
   for (ta = 0; ta < ntiles; ++ta) {
@@ -391,57 +392,69 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, cons
     }
     p -= cnt;
   }
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  // 16 x 16 sub-tiles of the 64 x 64 pair that hold columns < m; wave w owns sub-tile row w (f64 MFMA 16x16x4:
+  // a = A[i = l & 15][k = l >> 4], b = B[k = l >> 4][j = l & 15], C: col = l & 15, row = (l >> 4) + 4 reg)
+  const int ma = m - ta * kGT < kGT ? m - ta * kGT : kGT, mb = m - tb * kGT < kGT ? m - tb * kGT : kGT;
+  const int na = (ma + 15) / 16, nbt = (mb + 15) / 16;
+  const bool active = wave < na;
   const int64_t rows_per = ((d + gridDim.x - 1) / gridDim.x + kGT - 1) / kGT * kGT;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per;
   const int64_t r1 = r0 + rows_per < d ? r0 + rows_per : d;
-  double acc[4][4];
+  double4_t acc[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int j = 0; j < 4; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // On the diagonal pair only sub-tiles on or above the diagonal are formed (G is symmetric; k_gram_reduce mirrors).
+  const int j_lo = ta == tb ? wave : 0;
+  const int row = tid & 63;
   for (int64_t c0 = r0; c0 < r1; c0 += kGT) {
-    // load 64 rows x 64 cols of each tile: thread -> (col = e*4 + tid/64, row = tid%64): coalesced along rows
-#pragma unroll 4
+    // all loads of the chunk are issued before the first LDS store; columns beyond the last live sub-tile are not
+    // fetched and the diagonal pair loads its columns once.  (Prefetching chunk c + 1 into registers across the MFMA
+    // phase was measured slower: the allocator then needs > 256 VGPRs and the kernel drops to one workgroup per CU.)
+    const int64_t gi = c0 + row;
+    const bool rok = gi < r1;
+    const double wgt = rok ? rx[gi] * rx[gi] / Dx[gi] : 0.0;
+    double va[16], vb[16];
+#pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int col = e * 4 + (tid >> 6), row = tid & 63;
-      const int64_t gi = c0 + row;
+      const int col = e * 4 + (tid >> 6);
       const int ja = ta * kGT + col, jb = tb * kGT + col;
-      double va = 0.0, vb = 0.0;
-      if (gi < r1) {
-        const double wgt = rx[gi] * rx[gi] / Dx[gi];
-        if (ja < m) va = B[(int64_t)ja * d + gi] * wgt;
-        if (jb < m) vb = B[(int64_t)jb * d + gi];
-      }
-      As[row][col] = va;
-      Bs[row][col] = vb;
+      vb[e] = (col < 16 * nbt && rok && jb < m) ? B[(int64_t)jb * d + gi] : 0.0;
+      va[e] = ta == tb ? vb[e] : ((col < 16 * na && rok && ja < m) ? B[(int64_t)ja * d + gi] : 0.0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int col = e * 4 + (tid >> 6);
+      if (col < 16 * na) As[row][col] = va[e] * wgt;
+      if (col < 16 * nbt) Bs[row][col] = vb[e];
     }
     __syncthreads();
-#pragma unroll 8
-    for (int row = 0; row < kGT; ++row) {
-      double a[4], b[4];
+    if (active) {
+#pragma unroll 4
+      for (int kk = 0; kk < kGT; kk += 4) {
+        const double av = As[kk + lk][16 * wave + li];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = As[row][ty * 4 + q];
-        b[q] = Bs[row][tx * 4 + q];
+        for (int j = 0; j < 4; ++j)
+          if (j >= j_lo && j < nbt)
+            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[kk + lk][16 * j + li], acc[j], 0, 0, 0);
       }
-#pragma unroll
-      for (int qa = 0; qa < 4; ++qa)
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) acc[qa][qb] = fma(a[qa], b[qb], acc[qa][qb]);
     }
     __syncthreads();
   }
+  if (!active) return;
   double* dst = gpartial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kGT * kGT);
 #pragma unroll
-  for (int qa = 0; qa < 4; ++qa)
+  for (int j = 0; j < 4; ++j) {
+    if (j < j_lo || j >= nbt) continue;
 #pragma unroll
-    for (int qb = 0; qb < 4; ++qb) dst[(ty * 4 + qa) * kGT + tx * 4 + qb] = acc[qa][qb];
+    for (int r = 0; r < 4; ++r) dst[(16 * wave + lk + 4 * r) * kGT + 16 * j + li] = acc[j][r];
+  }
 }
-
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ gpartial, int nrb, int ntiles, int m,
                                                      double* __restrict__ G, int ldg) {
-  // grid (tile pairs, 16): each thread owns one of the 4096 tile outputs and sums the nrb row-block partials
+  // grid (tile pairs, 64): a workgroup owns 64 consecutive tile outputs; its 4 waves each sum a quarter of the nrb
+  // row-block partials (coalesced 512-byte rows, 4 independent chains), then the quarters are added in a fixed order.
   int ta = 0, tb = 0, p = blockIdx.x;
   for (ta = 0; ta < ntiles; ++ta) {
     const int cnt = ntiles - ta;
@@ -451,20 +464,32 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     }
     p -= cnt;
   }
+  __shared__ double red[4][64];
   const double* src = gpartial + (int64_t)blockIdx.x * nrb * (kGT * kGT);
-  const int o = blockIdx.y * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int o_out = blockIdx.y * 64 + lane;
+  const int a = ta * kGT + o_out / kGT, c = tb * kGT + o_out % kGT;
+  const bool live = a < m && c < m;  // k_gram writes only sub-tiles that hold columns < m
+  // diagonal pair: sub-tiles below the diagonal were not formed - read the mirrored entry
+  const bool mirror = ta == tb && (o_out / kGT) / 16 > (o_out % kGT) / 16;
+  const int o = mirror ? (o_out % kGT) * kGT + o_out / kGT : o_out;
+  const int per = (nrb + 3) / 4;
+  const int b0 = q * per, b1 = b0 + per < nrb ? b0 + per : nrb;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = 0;
-  for (; b + 3 < nrb; b += 4) {
-    s0 += src[(int64_t)b * (kGT * kGT) + o];
-    s1 += src[(int64_t)(b + 1) * (kGT * kGT) + o];
-    s2 += src[(int64_t)(b + 2) * (kGT * kGT) + o];
-    s3 += src[(int64_t)(b + 3) * (kGT * kGT) + o];
+  if (live) {
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      s0 += src[(int64_t)b * (kGT * kGT) + o];
+      s1 += src[(int64_t)(b + 1) * (kGT * kGT) + o];
+      s2 += src[(int64_t)(b + 2) * (kGT * kGT) + o];
+      s3 += src[(int64_t)(b + 3) * (kGT * kGT) + o];
+    }
+    for (; b < b1; ++b) s0 += src[(int64_t)b * (kGT * kGT) + o];
   }
-  for (; b < nrb; ++b) s0 += src[(int64_t)b * (kGT * kGT) + o];
-  const double s = (s0 + s1) + (s2 + s3);
-  const int a = ta * kGT + o / kGT, c = tb * kGT + o % kGT;
-  if (a < m && c < m) {
+  red[q][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && live) {
+    const double s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     G[(int64_t)a * ldg + c] = s;
     if (ta != tb) G[(int64_t)c * ldg + a] = s;
   }
@@ -1022,7 +1047,7 @@ int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B
     if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems) return FH_ESIZE;
     hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, st, B, rx, (const double*)Dx,
                        ctx->gpartial, d, m, ntiles);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 256), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
                        ntiles, m, G, ldg);
   } else {
     hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
