@@ -982,7 +982,7 @@ int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   const int64_t blocks = ((M + 63) / 64) * ((Cout + 63) / 64);
   const int nchunks = KH * KW * (Cin / kBK);
   int z = 1;
-  while (blocks * z < 192 && z < 8 && nchunks / (2 * z) >= 6) z *= 2;
+  while (blocks * z < 1024 && z < 8 && nchunks / (2 * z) >= 6) z *= 2;
   return z;
 }
 

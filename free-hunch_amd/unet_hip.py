@@ -57,10 +57,10 @@ def _split3(w):
 
 
 def _use_x6(N, H, W, rows_out):
-    """Measured on MI355X (scratch/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (and 1.05-1.1x
-    the Winograd one) once its 64/128-row tiles fill the chip; on the small grids (<= 16 x 16 at batch 8) the fp32
-    kernel with split-K is ~10 % faster."""
-    return rows_out > 64 and -(-(N * H * W) // 64) * -(-rows_out // 128) >= 256
+    """Measured on MI355X (scratch/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (1.05-1.1x the
+    Winograd one) on the large layers and, with the same deterministic split-K, 1.0-1.2x on the 8 x 8 ... 32 x 32 grids;
+    only the thin outputs (<= 64 rows: the 3 / 6 channel image convolutions) stay on the fp32 kernel."""
+    return rows_out > 64
 
 
 # conv arithmetic: "x6" = exact-split bf16 MFMA (fp32 accuracy, default), "wino" = fp32 MFMA + F(2,3), "f32" = fp32 MFMA only
@@ -115,13 +115,14 @@ class HipOps:
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      Ci, c.co, _lib.stream()), "fh_conv3x3_wino_nhwc")
             return out
-        if c.wx_f is not None and _use_x6(N, H, W, c.co):
-            _lib.check(self.lib.fh_conv2d_x6_nhwc(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
-                                                  None if res is None else res.data_ptr(), out.data_ptr(), None, 1, N, H,
-                                                  W, Ci, c.co, c.kh, c.kw, pad, 1, _lib.stream()), "fh_conv2d_x6_nhwc")
-            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
+        if c.wx_f is not None and _use_x6(N, H, W, c.co):
+            _lib.check(self.lib.fh_conv2d_x6_nhwc(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
+                                                  None if res is None else res.data_ptr(), out.data_ptr(),
+                                                  None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh,
+                                                  c.kw, pad, 1, _lib.stream()), "fh_conv2d_x6_nhwc")
+            return out
         _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
                                            None if res is None else res.data_ptr(), out.data_ptr(),
                                            None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co,
@@ -141,14 +142,14 @@ class HipOps:
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      c.co_p, c.ci, _lib.stream()), "fh_conv3x3_wino_nhwc(dgrad)")
             return out
-        if c.wx_d is not None and _use_x6(N, H, W, c.ci):
-            _lib.check(self.lib.fh_conv2d_x6_nhwc(g.data_ptr(), c.wx_d.data_ptr(), None,
-                                                  None if res is None else res.data_ptr(), out.data_ptr(), None, 1, N, H,
-                                                  W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()),
-                       "fh_conv2d_x6_nhwc(dgrad)")
-            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None
+        if c.wx_d is not None and _use_x6(N, H, W, c.ci):
+            _lib.check(self.lib.fh_conv2d_x6_nhwc(g.data_ptr(), c.wx_d.data_ptr(), None,
+                                                  None if res is None else res.data_ptr(), out.data_ptr(),
+                                                  None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p, c.ci, c.kh,
+                                                  c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_x6_nhwc(dgrad)")
+            return out
         _lib.check(self.lib.fh_conv2d_nhwc(g.data_ptr(), c.wd.data_ptr(), None,
                                            None if res is None else res.data_ptr(), out.data_ptr(),
                                            None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p,
