@@ -315,13 +315,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # FH_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 control flow on a one-GPU box - every rank uses cuda:0 and the
+    # collectives go through gloo on host copies (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("FH_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    coll = torch.device("cpu") if rehearsal else device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if rehearsal else "nccl")
     import __graft_entry__
-    if local == 0:
+    if rank == 0:
         __graft_entry__.build()  # no-op when free-hunch_amd/libfh_hip.so is up to date
     if world > 1:
         dist.barrier()  # the other ranks load the library only after rank 0 has (re)built it
@@ -341,8 +347,9 @@ def main():
         seeds = [(i * world + rank) * a.batch + j for j in range(a.batch)]
         out = run_batch(net, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir, a.groups)
         if world > 1:  # the path's one exchange: gather the finished uint8 images
-            bufs = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(bufs, out)
+            src = out.to(coll)
+            bufs = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(bufs, src)
         return out
 
     for i in range(a.warmup):
@@ -354,7 +361,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
