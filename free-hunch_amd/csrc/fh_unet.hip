@@ -551,6 +551,60 @@ __global__ __launch_bounds__(512) void k_conv_wino(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with a THIN output (Cout <= 8): the UNet's last convolution (128 -> 6 channels)
+// and the input gradient of its first one (128 -> 3).  A GEMM tile would be > 90 % padding there (measured 5-10 TFLOP/s);
+// this is a direct form instead: a workgroup owns a 16 x 16 pixel tile of one image, stages the 18 x 18 halo tile in
+// chunks of 32 channels through LDS (row stride 36 floats: conflict-free b128 reads), a thread owns one pixel and all
+// NO outputs, and the weights - uniform across the workgroup - arrive through the scalar path.  HBM-bound: the input is
+// read ~1.27x (halo), the output is NO floats per pixel.
+// ------------------------------------------------------------------------------------------------
+template <int NO>
+__global__ __launch_bounds__(256) void k_conv_thin(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int H,
+                                                   int W, int Cin, int Cout) {
+  constexpr int TS = 16, HS = TS + 2, LD = 36;
+  __shared__ __align__(16) float xs[HS * HS][LD];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const int64_t img = blockIdx.z;
+  const float* src = in + img * H * W * Cin;
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += 32) {
+    for (int idx = tid; idx < HS * HS * 8; idx += 256) {
+      const int pix = idx >> 3, c4 = (idx & 7) * 4;
+      const int gy = y0 + pix / HS - 1, gx = x0 + pix % HS - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+        v = *reinterpret_cast<const float4*>(src + ((int64_t)gy * W + gx) * Cin + c0 + c4);
+      *reinterpret_cast<float4*>(&xs[pix][c4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int p = (ty + tap / 3) * HS + tx + tap % 3;
+#pragma unroll
+      for (int c4 = 0; c4 < 32; c4 += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(&xs[p][c4]);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const float* wp = w + ((int64_t)(o < Cout ? o : 0) * 9 + tap) * Cin + c0 + c4;  // uniform: scalar loads
+          acc[o] = fmaf(v.x, wp[0], fmaf(v.y, wp[1], fmaf(v.z, wp[2], fmaf(v.w, wp[3], acc[o]))));
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int oy = y0 + ty, ox = x0 + tx;
+  if (oy >= H || ox >= W) return;
+  float* dst = out + ((img * H + oy) * W + ox) * Cout;
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+    if (o < Cout) dst[o] = acc[o] + (bias != nullptr ? bias[o] : 0.f);
+}
+
 // split-K epilogue: out = sum_z ws[z] + bias (+ res), fixed summation order
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
                                                        const float* __restrict__ res, float* __restrict__ out,
@@ -1048,6 +1102,19 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
     hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, bias, res, out, total,
                        Cout, ksplit);
   }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_conv3x3_thin_nhwc(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
+                         int Cout, void* stream) {
+  if (!in || !w || !out || N < 1 || N > 65535 || H < 1 || W < 1 || Cin < 32 || Cin % 32 != 0 || Cout < 1 || Cout > 8)
+    return FH_EINVAL;
+  const dim3 grid((W + 15) / 16, (H + 15) / 16, N);
+  if (Cout <= 4)
+    hipLaunchKernelGGL(k_conv_thin<4>, grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, Cin, Cout);
+  else
+    hipLaunchKernelGGL(k_conv_thin<8>, grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out, H, W, Cin, Cout);
   FH_LAUNCH_CHECK();
   return 0;
 }

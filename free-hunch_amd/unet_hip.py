@@ -115,6 +115,10 @@ class HipOps:
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      Ci, c.co, _lib.stream()), "fh_conv3x3_wino_nhwc")
             return out
+        if c.co <= 8 and c.kh == 3 and c.kw == 3 and res is None and H * W >= 4096:
+            _lib.check(self.lib.fh_conv3x3_thin_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(), out.data_ptr(), N, H, W,
+                                                     Ci, c.co, _lib.stream()), "fh_conv3x3_thin_nhwc")
+            return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         if c.wx_f is not None and _use_x6(N, H, W, c.co):
@@ -141,6 +145,10 @@ class HipOps:
             _lib.check(self.lib.fh_conv3x3_wino_nhwc(g.data_ptr(), c.wu_d.data_ptr(), None,
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
                                                      c.co_p, c.ci, _lib.stream()), "fh_conv3x3_wino_nhwc(dgrad)")
+            return out
+        if c.ci <= 8 and c.kh == 3 and c.kw == 3 and res is None and H * W >= 4096:
+            _lib.check(self.lib.fh_conv3x3_thin_nhwc(g.data_ptr(), c.wd.data_ptr(), None, out.data_ptr(), N, H, W, c.co_p,
+                                                     c.ci, _lib.stream()), "fh_conv3x3_thin_nhwc(dgrad)")
             return out
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None

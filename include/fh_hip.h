@@ -185,6 +185,11 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
                       int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
                       void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution with a thin output, Cout <= 8 (the 128 -> 6 output convolution and the
+ * 128 -> 3 input gradient of the first one): direct form, w [Cout][9][Cin] as for fh_conv2d_nhwc, Cin % 32 == 0. */
+int fh_conv3x3_thin_nhwc(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,
+                         int Cout, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution through a fused 1-D Winograd F(2,3) transform along W (W even, Cin % 16 == 0):
  * 1.5x fewer multiplies than fh_conv2d_nhwc at the same exact-fp32 MFMA.  wu is the pre-transformed weight
  * [4][Cout][3][Cin]:  wu[0] = w[.,.,ky,0], wu[1] = (w0+w1+w2)/2, wu[2] = (w0-w1+w2)/2, wu[3] = w[.,.,ky,2] over kx.

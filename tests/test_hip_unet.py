@@ -228,6 +228,24 @@ def test_conv_split_bf16_vs_float64(dev, shape):
     assert outs[0] <= 1.5 * outs[1] + 1e-7 * scale, (outs, scale)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128, 6), (1, 256, 256, 128, 3), (3, 33, 47, 64, 8), (1, 16, 16, 32, 1)])
+def test_conv_thin_vs_float64(dev, shape):
+    """fh_conv3x3_thin_nhwc (Cout <= 8, direct form) against float64."""
+    L, lib = _lib()
+    N, H, W, Ci, Co = shape
+    g = torch.Generator().manual_seed(sum(shape) + 9)
+    x = torch.randn(N, Ci, H, W, generator=g).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wf = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous()
+    out = torch.full((N, H, W, Co), float("nan"), device=dev)
+    L.check(lib.fh_conv3x3_thin_nhwc(xn.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), N, H, W, Ci, Co,
+                                     L.stream()), "thin")
+    assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
+
+
 def test_conv_split_bf16_splitk(dev):
     """K-split path of the split-bf16 kernel (small grids): partial sums through the workspace + fixed-order reduce."""
     from free_hunch_amd.unet_hip import _split3
