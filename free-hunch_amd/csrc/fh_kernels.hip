@@ -34,12 +34,12 @@ struct RtolArr {
 // ------------------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <bool BT, int T>  // T x T MFMA tiles (16x16) per wave: workgroup tile 32T x 32T
+template <bool BT, int TM, int TN = TM>  // TM x TN MFMA tiles (16x16) per wave: workgroup tile 32 TM x 32 TN
 __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                   int ldc, int64_t sA, int64_t sB, int64_t sC,
                                                   const fh_cg_state* __restrict__ states, int rows_per_plane) {
-  constexpr int BM = 32 * T, BN = 32 * T, BK = 32, LD = BK + 2;
+  constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = BK + 2;
   IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * BM) / rows_per_plane) / 3);
   __shared__ __align__(16) double As[2][BM][LD];
   __shared__ __align__(16) double Bs[2][BN][LD];
@@ -48,36 +48,42 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   C += sC * blockIdx.z;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 16 * T, wn = (wave & 1) * 16 * T;
+  const int wm = (wave >> 1) * 16 * TM, wn = (wave & 1) * 16 * TN;
   const int li = lane & 15, lk = lane >> 4;
-  double4_t acc[T][T];
+  double4_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < T; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < T; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TN; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
   // staging: BM rows x 32 k per operand = 4*T doubles per thread: row = (tid >> 3) + 32 * q, k segment (tid & 7) * 4
   const int srow = tid >> 3, sseg = (tid & 7) * 4;
-  double ra[T][4], rb[T][4];
+  double ra[TM][4], rb[TN][4];
   // full tiles (every DCT size that is a multiple of 64/32) take 16-byte loads; ragged edges fall back to guarded scalars
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0) && ((lda | ldb) % 2 == 0);
   auto load_chunk = [&](int k0) {  // global -> registers (issued one chunk ahead of its use)
 #pragma unroll
-    for (int q = 0; q < T; ++q) {
+    for (int q = 0; q < TM; ++q) {
       const int gm = m0 + srow + 32 * q;
       if (full) {
         const double2* pa = reinterpret_cast<const double2*>(A + (int64_t)gm * lda + k0 + sseg);
         const double2 a0 = pa[0], a1 = pa[1];
         ra[q][0] = a0.x, ra[q][1] = a0.y, ra[q][2] = a1.x, ra[q][3] = a1.y;
-        const double2* pb = BT ? reinterpret_cast<const double2*>(B + (int64_t)(n0 + srow + 32 * q) * ldb + k0 + sseg)
-                               : reinterpret_cast<const double2*>(B + (int64_t)(k0 + srow) * ldb + n0 + sseg + 32 * q);
-        const double2 b0 = pb[0], b1 = pb[1];
-        rb[q][0] = b0.x, rb[q][1] = b0.y, rb[q][2] = b1.x, rb[q][3] = b1.y;
         continue;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gk = k0 + sseg + e;
         ra[q][e] = (gm < M && gk < K) ? A[(int64_t)gm * lda + gk] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      if (full) {
+        const double2* pb = BT ? reinterpret_cast<const double2*>(B + (int64_t)(n0 + srow + 32 * q) * ldb + k0 + sseg)
+                               : reinterpret_cast<const double2*>(B + (int64_t)(k0 + srow) * ldb + n0 + sseg + 32 * q);
+        const double2 b0 = pb[0], b1 = pb[1];
+        rb[q][0] = b0.x, rb[q][1] = b0.y, rb[q][2] = b1.x, rb[q][3] = b1.y;
+        continue;
       }
       if (BT) {
         const int gn = n0 + srow + 32 * q;
@@ -98,9 +104,12 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < T; ++q) {
+    for (int q = 0; q < TM; ++q) {
       *reinterpret_cast<double2*>(&As[buf][srow + 32 * q][sseg]) = make_double2(ra[q][0], ra[q][1]);
       *reinterpret_cast<double2*>(&As[buf][srow + 32 * q][sseg + 2]) = make_double2(ra[q][2], ra[q][3]);
+    }
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
       if (BT) {
         *reinterpret_cast<double2*>(&Bs[buf][srow + 32 * q][sseg]) = make_double2(rb[q][0], rb[q][1]);
         *reinterpret_cast<double2*>(&Bs[buf][srow + 32 * q][sseg + 2]) = make_double2(rb[q][2], rb[q][3]);
@@ -119,25 +128,25 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
     if (more) load_chunk(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 4) {
-      double a[T], b[T];
+      double a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < T; ++i) a[i] = As[buf][wm + 16 * i + li][kk + lk];
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][wm + 16 * i + li][kk + lk];
 #pragma unroll
-      for (int j = 0; j < T; ++j) b[j] = Bs[buf][wn + 16 * j + li][kk + lk];
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][wn + 16 * j + li][kk + lk];
 #pragma unroll
-      for (int i = 0; i < T; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < T; ++j) {
+  for (int j = 0; j < TN; ++j) {
     const int gn = n0 + wn + 16 * j + li;
     if (gn >= N) continue;
 #pragma unroll
-    for (int i = 0; i < T; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gm = m0 + wm + 16 * i + lk + 4 * r;
@@ -152,33 +161,40 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
   const int S = ctx->S;
   if (planes > ctx->planes_max) return FH_ESIZE;
   const double* b1 = inverse ? ctx->basis_t : ctx->basis;
+  // Tile choice by workgroup count (256 CUs, the GEMMs are MFMA-bound: what matters is an even number of tile-units per
+  // CU).  64x64 tiles halve the LDS/global traffic per flop but S = 256, 24 planes gives 384 of them = 1.5 per CU
+  // (half the CUs carry two: 24 us); 64x32 tiles give 768 = exactly 3 half-size units per CU.
+  static const int force = getenv("FH_DCT_TILE") ? atoi(getenv("FH_DCT_TILE")) : 0;  // 1: 64x64, 2: 64x32, 3: 32x32
+  const int64_t n64 = (int64_t)((S + 63) / 64) * ((S + 63) / 64) * planes;
+  int tile = n64 >= 1024 ? 1 : ((int64_t)((S + 31) / 32) * ((S + 63) / 64) * planes >= 512 ? 2 : 3);
+  if (force) tile = force;
   // pass 1 (along W): T[r][k] = sum_n X[r][n] * b1[k][n]
-  {
-    // 64x64 workgroup tiles (2x2 MFMA tiles per wave, half the LDS/global traffic per flop) once they still give
-    // >= 1.5 workgroups per CU; otherwise 32x32 tiles to keep the chip populated
-    const bool big = (int64_t)((S + 63) / 64) * ((planes * S + 63) / 64) >= 384;
-    if (big) {
-      dim3 grid((S + 63) / 64, (planes * S + 63) / 64, 1);
-      hipLaunchKernelGGL((k_gemm_f64<true, 2>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                         (int64_t)0, (int64_t)0, (int64_t)0, states, S);
-    } else {
-      dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
-      hipLaunchKernelGGL((k_gemm_f64<true, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                         (int64_t)0, (int64_t)0, (int64_t)0, states, S);
-    }
+  if (tile == 1) {
+    dim3 grid((S + 63) / 64, (planes * S + 63) / 64, 1);
+    hipLaunchKernelGGL((k_gemm_f64<true, 2, 2>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+  } else if (tile == 2) {
+    dim3 grid((S + 31) / 32, (planes * S + 63) / 64, 1);
+    hipLaunchKernelGGL((k_gemm_f64<true, 2, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+  } else {
+    dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
+    hipLaunchKernelGGL((k_gemm_f64<true, 1, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
   }
   // pass 2 (along H), per plane: Y[k][w] = sum_n b1[k][n] * T[n][w]
-  {
-    const bool big = (int64_t)((S + 63) / 64) * ((S + 63) / 64) * planes >= 384;
-    if (big) {
-      dim3 grid((S + 63) / 64, (S + 63) / 64, planes);
-      hipLaunchKernelGGL((k_gemm_f64<false, 2>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                         S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
-    } else {
-      dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
-      hipLaunchKernelGGL((k_gemm_f64<false, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                         S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
-    }
+  if (tile == 1) {
+    dim3 grid((S + 63) / 64, (S + 63) / 64, planes);
+    hipLaunchKernelGGL((k_gemm_f64<false, 2, 2>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+  } else if (tile == 2) {
+    dim3 grid((S + 31) / 32, (S + 63) / 64, planes);
+    hipLaunchKernelGGL((k_gemm_f64<false, 2, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+  } else {
+    dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
+    hipLaunchKernelGGL((k_gemm_f64<false, 1, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
   }
   FH_LAUNCH_CHECK();
   return 0;
