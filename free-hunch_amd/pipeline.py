@@ -45,6 +45,26 @@ def psnr_u8(a, b):
     return 10 * torch.log10(255.0 ** 2 / mse)
 
 
+def ssim_u8(a, b, win_size=7, k1=0.01, k2=0.03):
+    """Mean structural similarity of uint8 image batches [N, C, H, W], the published algorithm with the defaults of
+    `skimage.metrics.structural_similarity(x, y, data_range=255, channel_axis=0)` as the reference calls it
+    (generate_conditional.py:546): 7x7 uniform window, sample covariance (NP / (NP - 1)), K1 = 0.01, K2 = 0.03,
+    float64, the (win_size - 1) / 2 border cropped, mean over pixels then over channels.  scikit-image is not
+    installed in this image, so this is pinned to a scipy.ndimage restatement (tests/test_metrics.py), not to skimage
+    itself: parity unpinned at that boundary."""
+    x, y = a.to(torch.float64), b.to(torch.float64)
+    n_p = win_size * win_size
+    cov_norm = n_p / (n_p - 1.0)
+    pool = lambda t: torch.nn.functional.avg_pool2d(t, win_size, stride=1)  # 'valid' window means = the cropped region
+    ux, uy = pool(x), pool(y)
+    vx = cov_norm * (pool(x * x) - ux * ux)
+    vy = cov_norm * (pool(y * y) - uy * uy)
+    vxy = cov_norm * (pool(x * y) - ux * uy)
+    c1, c2 = (k1 * 255.0) ** 2, (k2 * 255.0) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+    return s.mean(dim=(2, 3)).mean(dim=1)
+
+
 def list_images(path):
     exts = (".png", ".jpg", ".jpeg")
     files = []

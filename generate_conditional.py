@@ -7,7 +7,7 @@
 Same flags (free-hunch_amd/config.py), same outputs: DIR/images/{idx:06d}_{seed:06d}.png, cond_images/,
 forward_images/, results.txt.  Differences by design: images are sharded i -> rank i mod world with no per-image
 barrier, each rank runs `max_batch_size` images in lock-step, outputs are exchanged with one all_gather at the end,
-RNG is keyed by (seed, image index).  LPIPS needs a network download and is omitted; PSNR is computed on device.
+RNG is keyed by (seed, image index).  LPIPS needs a network download and is omitted; PSNR and SSIM are computed on device.
 `--synthetic_weights=ffhq|imagenet` runs with seeded random weights when no checkpoint is present."""
 import os
 import sys
@@ -24,7 +24,7 @@ def main(argv=None):
     from free_hunch_amd import unet as hu
     from free_hunch_amd.config import load_config
     from free_hunch_amd.measurements import get_operator
-    from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, psnr_u8, shard_indices
+    from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, psnr_u8, shard_indices, ssim_u8
     from free_hunch_amd.precond import iDDPMLinearPrecond
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
 
@@ -105,10 +105,10 @@ def main(argv=None):
             PIL.Image.fromarray(all_out[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(os.path.join(o.outdir, "images", name))
             PIL.Image.fromarray(all_cond[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(
                 os.path.join(o.outdir, "cond_images", name))
-        psnr = psnr_u8(all_out, all_cond)
+        psnr, ssim = psnr_u8(all_out, all_cond), ssim_u8(all_out, all_cond)
         with open(os.path.join(o.outdir, "results.txt"), "w") as f:
-            f.write(f"PSNR: {float(psnr.mean()):.4f}\nimages: {total}\n")
-        print(f"PSNR {float(psnr.mean()):.3f} dB over {total} images -> {o.outdir}", flush=True)
+            f.write(f"PSNR: {float(psnr.mean()):.4f}\nSSIM: {float(ssim.mean()):.4f}\nimages: {total}\n")
+        print(f"PSNR {float(psnr.mean()):.3f} dB, SSIM {float(ssim.mean()):.4f} over {total} images -> {o.outdir}", flush=True)
     for j, i in enumerate(mine):  # forward (measurement) images are written by the owning rank
         if fwds[j].shape[-1] == S:
             import PIL.Image
