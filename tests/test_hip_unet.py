@@ -286,3 +286,28 @@ def test_unet_ffhq256_hip_vs_torch_backend(dev):
         del m
     assert rel(outs[0][0], outs[1][0]) < 5e-4
     assert rel(outs[0][1], outs[1][1]) < 2e-3
+
+
+@pytest.mark.skipif(os.environ.get("FH_FULL_TESTS") != "1", reason="552 M parameters, ~1 min: runs with FH_FULL_TESTS=1")
+def test_unet_imagenet256_hip_vs_torch_backend(dev):
+    """The ImageNet-256 architecture (configs[0], [2], [4]: 42 ResBlocks, attention at 32 / 16 / 8 with T up to 1024) at
+    full size, batch 2: forward and input-VJP of the HIP backend against the PyTorch-ROCm backend, same seeded weights."""
+    from free_hunch_amd import unet as hu
+    cfg = hu.IMAGENET256
+    sd = hu.seeded_state(cfg, 1)
+    outs = []
+    x = (inputs.randn((2, 3, 256, 256), 18, torch.float32) * 0.5).to(dev)
+    t = torch.tensor([700, 40], device=dev)
+    cot = inputs.randn((2, 6, 256, 256), 19, torch.float32).to(dev)
+    for backend in ("hip", "torch"):
+        m = hu.UNetModel(cfg, backend=backend)
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        xi = x.clone().requires_grad_()
+        y = m(xi, t)
+        (gx,) = torch.autograd.grad((y * cot).sum(), xi)
+        outs.append((y.detach(), gx))
+        del m
+        torch.cuda.empty_cache()
+    assert rel(outs[0][0], outs[1][0]) < 5e-4
+    assert rel(outs[0][1], outs[1][1]) < 2e-3
