@@ -23,6 +23,7 @@ class FhProblem(C.Structure):
 
 
 FH_MAX_BATCH = 16
+FH_EINVAL, FH_ESIZE = -1, -2  # include/fh_hip.h
 
 
 class FhBatch(C.Structure):
@@ -48,6 +49,9 @@ _SIGS = {
     "fh_dot": ([C.c_void_p, c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_void_p], C.c_int),
     "fh_space_commit": ([C.c_void_p, c_dp, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,
                          c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_void_p], C.c_int),
+    "fh_space_commit_dev": ([C.c_void_p, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                             c_dp, C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p], C.c_int),
+    "fh_woodbury_inner": ([C.c_void_p, c_dp, C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_axpby": ([C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
     "fh_read_scalars": ([C.c_void_p, c_dp, C.POINTER(C.c_double), C.c_int, C.c_void_p], C.c_int),
     "fh_conv_circ": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

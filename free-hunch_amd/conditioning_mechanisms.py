@@ -302,13 +302,15 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             score_previous = (self.denoiser_means[-1] - self.xs[-1]) / self.sigmas[-1] ** 2
             cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous, only_covariance=True)
 
-    def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma):
+    def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma, std=None):
+        """`std`: (p_y_xt_grad * sigma^2).std() when the caller has already reduced it (the lock-step sampler does it for
+        the whole batch with one device -> host transfer instead of one per image)."""
         cm, rec, s = self.covariance_model, self._rec, float(sigma)
         sig2 = torch.as_tensor(sigma, dtype=F64, device=m_det.device).pow(2)
         if rec.get("analytic"):  # :277-278: always the VJP form
             p_y_xt_grad = p_y_xt_grad * self.cond_scaling
             rec["branch"] = "vjp"
-        elif (p_y_xt_grad * sig2).std() > self.denoiser_mean_error_threshold:
+        elif (std if std is not None else (p_y_xt_grad * sig2).std()) > self.denoiser_mean_error_threshold:
             p_y_xt_grad = cm.denoiser_cov_vector_dot(mat.detach(), use_cuda=True) * self.cond_scaling / sig2
             rec["branch"] = "cov"
         else:

@@ -30,25 +30,29 @@ F64 = torch.float64
 
 
 class _Rep:
-    """One representation over a shared base: diagonal D, row scale r, inner matrix M."""
+    """One representation over a shared base: diagonal D, row scale r, inner matrix M (m x m, device-resident in
+    `M_dev[:m, :m]`; `.M` downloads it - tests and get_dense_matrices only)."""
 
     def __init__(self, D, m_cap):
         self.D = D
         self.r = torch.ones_like(D)
-        self.M = np.zeros((0, 0))
+        self.m = 0
         self.M_dev = torch.zeros(m_cap, m_cap, dtype=F64, device=D.device)
 
+    @property
+    def M(self):
+        return self.M_dev[: self.m, : self.m].cpu().numpy()
+
     def set_M(self, M):
-        self.M = M
         m = M.shape[0]
+        self.m = m
         if m:
             self.M_dev[:m, :m].copy_(torch.from_numpy(np.ascontiguousarray(M)))
 
     def grow(self, m_cap):
         new = torch.zeros(m_cap, m_cap, dtype=F64, device=self.D.device)
-        m = self.M.shape[0]
-        if m:
-            new[:m, :m].copy_(self.M_dev[:m, :m])
+        if self.m:
+            new[: self.m, : self.m].copy_(self.M_dev[: self.m, : self.m])
         self.M_dev = new
 
 
@@ -128,14 +132,23 @@ class CovarianceHessianBFGS:
         self.m_cap = cap
 
     def _invert(self, src, dst, fam, shift=0.0):
-        """dst <- (src + shift*I)^-1 over the family's base; src.D is shifted in place."""
+        """dst <- (src + shift*I)^-1 over the family's base; src.D is shifted in place.  No host round trip for
+        m <= 64: the Gram matrix stays on the device and fh_woodbury_inner forms dst.M there."""
         m = fam.m
+        assert src.m == m, (src.m, m)
         self.ctx.rep_invert(src.D, src.r, fam.B, shift, dst.D, dst.r, self._G, m)
-        if m:
-            G = self._G[:m, :m].cpu().numpy()
-            dst.set_M(_woodbury_inner(src.M, G))
-        else:
-            dst.set_M(np.zeros((0, 0)))
+        if m == 0:
+            dst.m = 0
+            return
+        ctx = self.ctx
+        rc = ctx.lib.fh_woodbury_inner(ctx.h, _lib.ptr(src.M_dev), src.M_dev.shape[1], _lib.ptr(self._G),
+                                       self._G.shape[1], _lib.ptr(dst.M_dev), dst.M_dev.shape[1], m, _lib.stream())
+        if rc == 0:
+            dst.m = m
+            return
+        if rc != _lib.FH_ESIZE:
+            _lib.check(rc, "fh_woodbury_inner")
+        dst.set_M(_woodbury_inner(src.M, self._G[:m, :m].cpu().numpy()))  # m > 64: host LU
 
     def _apply(self, rep, fam, z, out):
         return self.ctx.rep_apply(rep.D, rep.r, fam.B, rep.M_dev, z, out, fam.m)
@@ -147,7 +160,7 @@ class CovarianceHessianBFGS:
         self.famH.m = 0
         for rep in (self.C, self.Ci, self.H, self.Hi):
             rep.r.fill_(1.0)
-            rep.set_M(np.zeros((0, 0)))
+            rep.m = 0
         self._invert(self.C, self.Ci, self.famC)
         torch.div(self.C.D, s2, out=self.H.D)
         self.H.D.sub_(1.0).div_(s2)
@@ -211,22 +224,21 @@ class CovarianceHessianBFGS:
                    "fh_space_prep")
         cdx = self._apply(self.C, self.famC, dx, self._t2)
         _lib.check(lib.fh_dot(ctx.h, _lib.ptr(cdx), _lib.ptr(dx), _lib.ptr(self._scal), 1, d, st), "fh_dot")
-        dx_de, q = ctx.read_scalars(self._scal, 2)
-        gamma = 1.0 / dx_de
+        # gamma = 1 / (dx.de) and q = dx.(C dx) stay on the device (self._scal): the commit kernel reads them there and
+        # appends diag(gamma, -1/q) to the inner matrices itself
         project = bool(self.project_to_diagonal)
         mc, mh = self.famC.m, self.famH.m
         self._ensure_capacity(max(mc if project else mc + 2, mh + 2))
         Bc, Bh = self.famC.B, self.famH.B
-        _lib.check(lib.fh_space_commit(
-            ctx.h, _lib.ptr(de), _lib.ptr(cdx), gamma, q, s2, _lib.ptr(self.C.D), _lib.ptr(self.C.r),
+        _lib.check(lib.fh_space_commit_dev(
+            ctx.h, _lib.ptr(de), _lib.ptr(cdx), _lib.ptr(self._scal), s2, _lib.ptr(self.C.D), _lib.ptr(self.C.r),
             None if project else Bc[mc].data_ptr(), None if project else Bc[mc + 1].data_ptr(),
-            _lib.ptr(self.H.D), _lib.ptr(self.H.r), Bh[mh].data_ptr(), Bh[mh + 1].data_ptr(), int(project), d, st),
-            "fh_space_commit")
+            _lib.ptr(self.H.D), _lib.ptr(self.H.r), Bh[mh].data_ptr(), Bh[mh + 1].data_ptr(),
+            _lib.ptr(self.C.M_dev), self.C.M_dev.shape[1], mc, _lib.ptr(self.H.M_dev), self.H.M_dev.shape[1], mh,
+            int(project), d, st), "fh_space_commit_dev")
         if not project:
-            self.famC.m = mc + 2
-            self.C.set_M(_blockdiag(self.C.M, gamma, -1.0 / q))
-        self.famH.m = mh + 2
-        self.H.set_M(_blockdiag(self.H.M, gamma / s2 ** 2, -1.0 / (q * s2 ** 2)))
+            self.famC.m = self.C.m = mc + 2
+        self.famH.m = self.H.m = mh + 2
         self._invert(self.C, self.Ci, self.famC)
         self._invert(self.H, self.Hi, self.famH)
         if self.max_vector_count is not None:
@@ -247,17 +259,9 @@ class CovarianceHessianBFGS:
         out = []
         for rep, fam in ((self.C, self.famC), (self.Ci, self.famC), (self.H, self.famH), (self.Hi, self.famH)):
             W = (fam.B[: fam.m] * rep.r[None, :]).T
-            M = torch.from_numpy(np.ascontiguousarray(rep.M)).to(self.device)
+            M = rep.M_dev[: rep.m, : rep.m]
             out.append(torch.diag(rep.D) + W @ M @ W.T)
         return tuple(out)
-
-
-def _blockdiag(M, a, b):
-    m = M.shape[0]
-    out = np.zeros((m + 2, m + 2))
-    out[:m, :m] = M
-    out[m, m], out[m + 1, m + 1] = a, b
-    return out
 
 
 def _lib_max_cols():

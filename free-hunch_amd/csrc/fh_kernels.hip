@@ -589,12 +589,43 @@ __global__ __launch_bounds__(256) void k_space_prep(const double* __restrict__ d
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// scal != null: gamma = 1 / scal[0] (dx.de) and q = scal[1] (dx.C dx) are read on the device, and workgroup 0 appends the
+// pair to the inner matrices: Mc gets diag(gamma, -1/q) at (mc, mc+1) unless projected, Mh diag(gamma, -1/q) / s2^2 at
+// (mh, mh+1); the new rows / columns are cleared first.  No scalar returns to the host.
 __global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__ de, const double* __restrict__ cdx,
                                                       double gamma, double q, double s2, double* __restrict__ Dc,
                                                       const double* __restrict__ rc, double* __restrict__ bc0,
                                                       double* __restrict__ bc1, double* __restrict__ Dh,
                                                       const double* __restrict__ rh, double* __restrict__ bh0,
-                                                      double* __restrict__ bh1, int project, int64_t n) {
+                                                      double* __restrict__ bh1, int project, int64_t n,
+                                                      const double* __restrict__ scal, double* __restrict__ Mc, int ldc,
+                                                      int mc, double* __restrict__ Mh, int ldh, int mh) {
+  if (scal != nullptr) {
+    gamma = 1.0 / scal[0];
+    q = scal[1];
+    if (blockIdx.x == 0) {
+      const int t = threadIdx.x;
+      if (!project && Mc != nullptr) {
+        for (int i = t; i < mc + 2; i += 256)
+          for (int e = 0; e < 2; ++e) Mc[(int64_t)(mc + e) * ldc + i] = 0.0, Mc[(int64_t)i * ldc + mc + e] = 0.0;
+      }
+      if (Mh != nullptr) {
+        for (int i = t; i < mh + 2; i += 256)
+          for (int e = 0; e < 2; ++e) Mh[(int64_t)(mh + e) * ldh + i] = 0.0, Mh[(int64_t)i * ldh + mh + e] = 0.0;
+      }
+      __syncthreads();
+      if (t == 0) {
+        if (!project && Mc != nullptr) {
+          Mc[(int64_t)mc * ldc + mc] = gamma;
+          Mc[(int64_t)(mc + 1) * ldc + mc + 1] = -1.0 / q;
+        }
+        if (Mh != nullptr) {
+          Mh[(int64_t)mh * ldh + mh] = gamma / (s2 * s2);
+          Mh[(int64_t)(mh + 1) * ldh + mh + 1] = -1.0 / (q * s2 * s2);
+        }
+      }
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const double e = de[i], c = cdx[i];
     double dc = Dc[i];
@@ -715,6 +746,89 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ 
   }
   if (add != nullptr) acc = fma(add_scale, add[o], acc);
   out[o] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The m x m part of a Woodbury step on the device:  Mdst = sym( -Msrc (I + G Msrc)^-1 )   (online_update_bfgs.py:87-119
+// in the real form of this build).  One workgroup, everything in LDS: A = I + G Msrc is formed, then X A = -Msrc is
+// solved as A^T X^T = -Msrc^T by Gauss-Jordan elimination with partial pivoting on the augmented [A^T | -Msrc^T]
+// (m <= 64: 64 x 129 doubles).  This replaces a device -> host copy of G, numpy.linalg.inv and a host -> device copy of
+// the result: the covariance updates of a guidance call then run without a single host round trip.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWbMax = 64;
+
+__global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict__ Msrc, int lds_, const double* __restrict__ G,
+                                                        int ldg, double* __restrict__ Mdst, int ldd, int m) {
+  extern __shared__ __align__(16) double wb[];
+  const int w = 2 * m + 1;          // row pitch of the augmented matrix (odd: conflict-free column walks)
+  double* aug = wb;                 // [m][w]   left: A^T, right: -Msrc^T
+  double* Ms = wb + m * w;          // [m][m+1] Msrc
+  double* Gs = Ms + m * (m + 1);    // [m][m+1] G
+  __shared__ int piv;
+  __shared__ double pval;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < m * m; i += 256) {
+    const int r = i / m, c = i % m;
+    Ms[r * (m + 1) + c] = Msrc[(int64_t)r * lds_ + c];
+    Gs[r * (m + 1) + c] = G[(int64_t)r * ldg + c];
+  }
+  __syncthreads();
+  // A = I + G Msrc;  aug[r][c] = A^T[r][c] = A[c][r];  aug[r][m + c] = -Msrc^T[r][c] = -Msrc[c][r]
+  for (int i = tid; i < m * m; i += 256) {
+    const int r = i / m, c = i % m;
+    double a = r == c ? 1.0 : 0.0;
+    for (int k = 0; k < m; ++k) a = fma(Gs[c * (m + 1) + k], Ms[k * (m + 1) + r], a);
+    aug[r * w + c] = a;
+    aug[r * w + m + c] = -Ms[c * (m + 1) + r];
+  }
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    // pivot search in column k, rows k..m-1 (one wave, deterministic: the first maximum wins)
+    if (tid < 64) {
+      double best = -1.0;
+      int bi = k;
+      for (int r = k + tid; r < m; r += 64) {
+        const double v = fabs(aug[r * w + k]);
+        if (v > best) best = v, bi = r;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o, 64);
+        const int oi = __shfl_down(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+      }
+      if (tid == 0) piv = bi;
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k)
+      for (int c = tid; c < 2 * m; c += 256) {
+        const double t = aug[k * w + c];
+        aug[k * w + c] = aug[p * w + c];
+        aug[p * w + c] = t;
+      }
+    __syncthreads();
+    if (tid == 0) pval = aug[k * w + k];
+    __syncthreads();
+    const double inv = 1.0 / pval;
+    for (int c = tid; c < 2 * m; c += 256) aug[k * w + c] *= inv;
+    __syncthreads();
+    // eliminate column k from every other row: thread -> (row, column slice)
+    for (int i = tid; i < m * 2 * m; i += 256) {
+      const int r = i / (2 * m), c = i % (2 * m);
+      if (r == k || c == k) continue;  // column k itself is cleared after the sweep (its old value is the multiplier)
+      aug[r * w + c] = fma(-aug[r * w + k], aug[k * w + c], aug[r * w + c]);
+    }
+    __syncthreads();
+    for (int r = tid; r < m; r += 256)
+      if (r != k) aug[r * w + k] = 0.0;
+    __syncthreads();
+  }
+  // right half = X^T; Mdst = 0.5 (X + X^T)
+  for (int i = tid; i < m * m; i += 256) {
+    const int r = i / m, c = i % m;
+    Mdst[(int64_t)r * ldd + c] = 0.5 * (aug[c * w + m + r] + aug[r * w + m + c]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1229,7 +1343,37 @@ int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double
   if (!ctx || !de || !cdx || !Dc || !Dh || !Bh_col0 || !Bh_col1) return FH_EINVAL;
   if (!project && (!Bc_col0 || !Bc_col1)) return FH_EINVAL;
   hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, gamma, q, s2, Dc, rc,
-                     Bc_col0, Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d);
+                     Bc_col0, Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d, (const double*)nullptr, (double*)nullptr, 0, 0,
+                     (double*)nullptr, 0, 0);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_space_commit_dev(fh_context* ctx, const double* de, const double* cdx, const double* scal, double s2, double* Dc,
+                        const double* rc, double* Bc_col0, double* Bc_col1, double* Dh, const double* rh,
+                        double* Bh_col0, double* Bh_col1, double* Mc, int ldc, int mc, double* Mh, int ldh, int mh,
+                        int project, int64_t d, void* stream) {
+  if (!ctx || !de || !cdx || !scal || !Dc || !Dh || !Bh_col0 || !Bh_col1 || !Mh || mh < 0 || ldh < mh + 2) return FH_EINVAL;
+  if (!project && (!Bc_col0 || !Bc_col1 || !Mc || mc < 0 || ldc < mc + 2)) return FH_EINVAL;
+  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, 0.0, 0.0, s2, Dc, rc, Bc_col0,
+                     Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d, scal, Mc, ldc, mc, Mh, ldh, mh);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
+                      int m, void* stream) {
+  if (!ctx || m < 0 || (m > 0 && (!Msrc || !G || !Mdst || ld_src < m || ldg < m || ld_dst < m))) return FH_EINVAL;
+  if (m == 0) return 0;
+  if (m > kWbMax) return FH_ESIZE;  // the caller falls back to its host path
+  const size_t lds = ((size_t)m * (2 * m + 1) + 2 * (size_t)m * (m + 1)) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_woodbury_inner),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_woodbury_inner, dim3(1), dim3(256), lds, (hipStream_t)stream, Msrc, ld_src, G, ldg, Mdst, ld_dst, m);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -54,7 +54,7 @@ int fh_rep_apply(fh_context* ctx, const double* D, const double* r, const double
  *   Dy      <- 1 / Dx
  *   ry      <- rx / Dx
  *   G[a][b] <- sum_i B[a][i] B[b][i] rx[i]^2 / Dx[i]      (m x m, ld = ldg, device)
- * The caller finishes with the m x m algebra  My = -Mx (I + G Mx)^-1  (host, float64). */
+ * The caller finishes with the m x m algebra  My = -Mx (I + G Mx)^-1  (fh_woodbury_inner on the device; float64). */
 int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,
                   double* ry, double* G, int ldg, int64_t d, int m, void* stream);
 
@@ -70,6 +70,20 @@ int fh_dot(fh_context* ctx, const double* a, const double* b, double* scal, int 
 int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double gamma, double q, double s2,
                     double* Dc, const double* rc, double* Bc_col0, double* Bc_col1, double* Dh, const double* rh,
                     double* Bh_col0, double* Bh_col1, int project, int64_t d, void* stream);
+/* fh_space_commit without the host in the loop: gamma = 1 / scal[0] and q = scal[1] are read from the DEVICE scalars
+ * that fh_space_prep / fh_dot wrote, and the pair is appended to the inner matrices on the device as well
+ * (Mc: diag(gamma, -1/q) at rows/cols mc, mc+1 unless project; Mh: the same divided by s2^2 at mh, mh+1). */
+int fh_space_commit_dev(fh_context* ctx, const double* de, const double* cdx, const double* scal, double s2, double* Dc,
+                        const double* rc, double* Bc_col0, double* Bc_col1, double* Dh, const double* rh,
+                        double* Bh_col0, double* Bh_col1, double* Mc, int ldc, int mc, double* Mh, int ldh, int mh,
+                        int project, int64_t d, void* stream);
+
+/* The m x m algebra of the Woodbury step above on the device (m <= 64; FH_ESIZE beyond, the caller then uses its host
+ * path):  Mdst[:m,:m] = sym( -Msrc (I + G Msrc)^-1 ), Gauss-Jordan with partial pivoting in one workgroup.
+ * Replaces the D2H copy + numpy.linalg.inv + H2D copy of an update, so that update_time_step / update_space_step
+ * (online_update_bfgs.py:153-192, 250-312) run without a host round trip. */
+int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
+                      int m, void* stream);
 
 /* out = alpha*a + beta*b (b may be null when beta == 0); the few remaining elementwise steps of the
  * time update (mean' = x + sigma'^2 score', online_update_bfgs.py:178-180). */

@@ -499,3 +499,30 @@ def test_rep_apply_batched_matches_single(dev):
         assert torch.equal(one, out[i]), i
         ref = Ds[i] * z[i] + rs[i] * (Bs[i].T @ (Ms[i][:m, :m] @ (Bs[i] @ (rs[i] * z[i]))))
         assert maxabs(one, ref) < 1e-9 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("m", [1, 2, 7, 32, 64])
+def test_woodbury_inner_on_device_matches_numpy(dev, m):
+    """fh_woodbury_inner (Gauss-Jordan with partial pivoting in one workgroup) against the host formula
+    -M (I + G M)^-1 (numpy LU), on Gram-like G and an indefinite block-diagonal-plus-noise M as the updates produce."""
+    from free_hunch_amd import _lib
+    from free_hunch_amd.covariance import _woodbury_inner
+    ctx = _lib.Context.get(16, 3, 64)
+    g = np.random.default_rng(100 + m)
+    W = g.standard_normal((m, 3 * m + 5))
+    G = W @ W.T / (3 * m + 5)
+    M = np.diag(g.standard_normal(m) * 2.0) + 0.05 * g.standard_normal((m, m))
+    M = 0.5 * (M + M.T)
+    ref = _woodbury_inner(M, G)
+    ld = 80
+    Md = torch.zeros(ld, ld, dtype=F64, device=dev)
+    Gd = torch.zeros(ld, ld, dtype=F64, device=dev)
+    Od = torch.full((ld, ld), float("nan"), dtype=F64, device=dev)
+    Md[:m, :m] = torch.from_numpy(M)
+    Gd[:m, :m] = torch.from_numpy(G)
+    _lib.check(ctx.lib.fh_woodbury_inner(ctx.h, Md.data_ptr(), ld, Gd.data_ptr(), ld, Od.data_ptr(), ld, m, _lib.stream()),
+               "fh_woodbury_inner")
+    got = Od[:m, :m].cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    assert torch.isnan(Od[m:, :]).all() and torch.isnan(Od[:m, m:]).all()  # nothing outside [:m, :m] is touched
+    assert ctx.lib.fh_woodbury_inner(ctx.h, Md.data_ptr(), ld, Gd.data_ptr(), ld, Od.data_ptr(), ld, 65, _lib.stream()) < 0
