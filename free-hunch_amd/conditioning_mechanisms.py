@@ -17,6 +17,7 @@ import math
 import os
 from warnings import warn
 
+import numpy as np
 import torch
 from torch.autograd import grad
 
@@ -30,8 +31,11 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 def choose_conditioning_mechanism(name):
     if name == "online_covariance":
         return BFGSOnlineUpdate
-    if name in ("dps", "pigdm", "pigdm_videodiff_schedule", "peng_convert", "peng_analytic", "tmpd", "diffpir"):
-        raise NotImplementedError(f"'{name}' is a comparison method of the reference, outside the Free Hunch hot path")
+    if name in _BASELINES:
+        return _BASELINES[name]
+    if name in ("peng_convert", "tmpd"):
+        raise NotImplementedError(f"'{name}' needs the per-pixel-variance scipy solver of the reference "
+                                  "(conditioning_mechanisms.py:360-381), which is outside this build")
     if name == "ddnm":
         raise ValueError("DDNM conditioning mechanism not implemented in this branch of the codebase")
     raise ValueError(f"Unknown conditioning mechanism: {name}")
@@ -325,3 +329,95 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self.xs.append(x_det)
         self.denoiser_means.append(m_det)
         return x_0_mean_new
+
+
+
+# ---------------------------------------------------------------------------------------------- comparison methods
+# The scalar-variance methods of the reference on the same operator / UNet-VJP kernels.  Their mat solver
+# is mat = A^T (theta A A^T + sigma_y^2 I)^-1 (y - A x0) with a scalar theta (the Fourier closed forms
+# conditioning_mechanisms.py:357, :454, :608); here that system goes through the device CG with C = theta I to 1e-10.
+def _scalar_mat(operator, y, x0_mean, theta, data_dim):
+    scal = ScalarCovariance(float(theta), data_dim, x0_mean.device, getattr(operator, "ctx_slot", 0))
+    return solve_customcuda(operator, y, x0_mean.detach(), scal, 1.0, 1.0, None, rtol=1e-10)
+
+
+class _ScalarVarianceMechanism(ConditioningMechanism):
+    def __init__(self, cond_scaling, forward_operator, clip_x0_mean, init_denoiser_variance=None,
+                 init_noise_variance=None, data_dim=None, pigdm_posthoc_scaling=True, **argv):
+        super().__init__(cond_scaling, forward_operator, clip_x0_mean)
+        self.pigdm_posthoc_scaling = pigdm_posthoc_scaling
+        self.data_dim = data_dim if data_dim is not None else int(np.prod(forward_operator.in_shape[1:]))
+        self.mle_sigma_thres = 0.2
+        self.argv = argv
+
+    def _variance(self, sigma):
+        raise NotImplementedError
+
+    def _scale(self, x0_var):
+        return self.cond_scaling
+
+    def x0_mean_update(self, x_t, model, y, sigma):
+        x_t = x_t.requires_grad_()
+        x_0_mean, _ = model(x_t, sigma)
+        x0_var = self._variance(sigma)
+        mat = _scalar_mat(self.forward_operator, y, x_0_mean, x0_var, self.data_dim)
+        p_y_xt_grad = grad((mat.detach() * x_0_mean).sum(), x_t)[0] * self._scale(x0_var)
+        return x_0_mean + p_y_xt_grad * sigma.pow(2)
+
+
+class PiGDM(_ScalarVarianceMechanism):  # conditioning_mechanisms.py:134-152
+    def _variance(self, sigma):
+        return sigma.pow(2) / (1 + sigma.pow(2))
+
+    def _scale(self, x0_var):
+        return (x0_var if self.pigdm_posthoc_scaling else 1) * self.cond_scaling
+
+
+class PiGDM_Videodiff_schedule(_ScalarVarianceMechanism):  # :154-171
+    def _variance(self, sigma):
+        return sigma.pow(2)
+
+
+class PengAnalytic(_ScalarVarianceMechanism):  # :87-110
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.recon_mse = torch.load(os.path.join(_DATA, "recon_mse.pt"), weights_only=True)
+
+    def _variance(self, sigma):
+        if sigma < self.mle_sigma_thres:
+            idx = (self.recon_mse["sigmas"].to(sigma.device) - sigma).abs().argmin()
+            return self.recon_mse["mse_list"][idx].to(sigma.device)
+        return sigma.pow(2) / (1 + sigma.pow(2))
+
+
+class DiffPIR(ConditioningMechanism):  # :173-188
+    def __init__(self, cond_scaling, forward_operator, clip_x0_mean, **argv):
+        super().__init__(cond_scaling, forward_operator, clip_x0_mean)
+        self.lambda_ = argv["diffpir_lambda"]
+        self.data_dim = int(np.prod(forward_operator.in_shape[1:]))
+
+    def x0_mean_update(self, x_t, model, y, sigma):
+        assert self.lambda_ is not None, "lambda_ must be specified for DiffPIR guidance"
+        with torch.no_grad():
+            x0_mean, _ = model(x_t, sigma)
+        x0_var = sigma.pow(2) / self.lambda_
+        mat = _scalar_mat(self.forward_operator, y, x0_mean, x0_var, self.data_dim)
+        return x0_mean + mat * x0_var
+
+
+class DPS(ConditioningMechanism):  # :52-63
+    def x0_mean_update(self, x_t, model, y, sigma):
+        x_t = x_t.requires_grad_()
+        x_0_mean, _ = model(x_t, sigma)
+        op = self.forward_operator
+        with torch.no_grad():
+            difference = y.to(x_0_mean.dtype) - op.forward(x_0_mean.detach(), noiseless=True)
+            # -d||difference|| / d x0 = A^T difference / ||difference||: the operators run on HIP kernels without autograd,
+            # so their exact adjoint supplies the cotangent of the UNet's input-VJP
+            cot = op.forward_adjoint(difference / torch.linalg.norm(difference))
+        p_y_xt_grad = grad((cot * x_0_mean).sum(), x_t)[0] * self.cond_scaling
+        return x_0_mean + p_y_xt_grad * sigma.pow(2)
+
+
+_BASELINES = {"dps": DPS, "pigdm": PiGDM, "pigdm_videodiff_schedule": PiGDM_Videodiff_schedule,
+              "peng_analytic": PengAnalytic, "diffpir": DiffPIR}

@@ -151,6 +151,10 @@ class _BlurOperator(LinearOperator):
             y = y.reshape(y.shape[0], *self.in_shape[-3:])
         return self._conv(y, adjoint=True).to(y.dtype)
 
+    def forward_adjoint(self, v):
+        """exact adjoint of the noiseless `forward`, for DPS"""
+        return self._conv(v, adjoint=True).to(v.dtype)
+
     def get_kernel(self):
         return self.taps.kernel.view(1, 1, self.kernel_size, self.kernel_size).to(self.device)
 
@@ -220,6 +224,11 @@ class SuperResolutionOperator(LinearOperator):  # measurements.py:87-123
             y = y.reshape(y.shape[0], *self.out_shape[-3:])
         return self._conv(y, stride=self.scale_factor, adjoint=True).to(y.dtype)
 
+    def forward_adjoint(self, v):
+        """exact adjoint of the noiseless `forward` (the antialiased bicubic Resizer), for DPS"""
+        R = self._R.to(v.dtype)
+        return torch.einsum("oh,pw,ncop->nchw", R, R, v.to(self.device))
+
     def get_kernel(self):
         return self.taps.kernel.view(1, 1, *self.taps.kernel.shape).to(self.device)
 
@@ -238,6 +247,9 @@ class InpaintingOperator(LinearOperator):  # measurements.py:204-246
             idx = torch.where(self.mask > 0)
             return y, y[..., idx[-3], idx[-2], idx[-1]]
         return y
+
+    def forward_adjoint(self, v):
+        return v * self.mask.to(v.dtype)
 
     def transpose(self, data, flatten=False):
         y = data.clone()

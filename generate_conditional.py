@@ -26,13 +26,13 @@ def main(argv=None):
     from free_hunch_amd.measurements import get_operator
     from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, psnr_u8, shard_indices, ssim_u8
     from free_hunch_amd.precond import iDDPMLinearPrecond
-    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
+    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler, conditional_sampler_batched
 
     o = load_config(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if o.conditioning_mechanism != "online_covariance":
-        raise NotImplementedError("only the Free Hunch plugin ('online_covariance') is implemented on MI355X")
+    from free_hunch_amd.conditioning_mechanisms import choose_conditioning_mechanism
+    choose_conditioning_mechanism(o.conditioning_mechanism)  # raises for unknown / unsupported names up front
     if o.iddpm_preconditioning != "linear":
         raise NotImplementedError("cosine preconditioning is incompatible with the plugin API in the reference too")
     torch.cuda.set_device(local)
@@ -86,8 +86,14 @@ def main(argv=None):
             ops.append(op)
             ys.append(op.forward(enc.encode(img[None].to(device)), noiseless=False))
             noise.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(key), dtype=torch.float32))
-        x = conditional_sampler_batched(net, torch.cat(noise).to(device), ys, ops, num_steps=o.num_steps,
-                                        sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver, **kw)
+        if o.conditioning_mechanism == "online_covariance":
+            x = conditional_sampler_batched(net, torch.cat(noise).to(device), ys, ops, num_steps=o.num_steps,
+                                            sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver, **kw)
+        else:  # the scalar-variance comparison methods run image by image (batch 1, as in the reference)
+            x = torch.cat([conditional_sampler(net, noise[b].to(device), None, None, num_steps=o.num_steps,
+                                               sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver,
+                                               measurement=ys[b], operator=ops[b], **kw)[0].detach()
+                           for b in range(len(ops))])
         outs.append(enc.decode(x))
         conds.append(torch.stack(imgs).to(device))
         fwds += [enc.decode(y) for y in ys]

@@ -571,6 +571,55 @@ class OracleFreeHunch:
 # --------------------------------------------------------------------------
 # a1  conditional_sampler   generate_conditional.py:38-169  (edm / linear / none, S_churn = 0)
 # --------------------------------------------------------------------------
+# --------------------------------------------------------------------------
+# scalar-variance comparison methods   conditioning_mechanisms.py:52-63 (DPS), :87-110 (PengAnalytic), :134-152 (PiGDM),
+# :154-171 (PiGDM video-diffusion schedule), :173-188 (DiffPIR); their mat solvers are the closed forms of analytic_mat
+# --------------------------------------------------------------------------
+class OracleBaseline:
+    def __init__(self, kind, cond_scaling, forward_operator, clip_x0_mean, pigdm_posthoc_scaling=False,
+                 diffpir_lambda=None, recon_mse=None):
+        assert kind in ("dps", "pigdm", "pigdm_videodiff_schedule", "diffpir", "peng_analytic")
+        self.kind, self.cond_scaling, self.op, self.clip = kind, cond_scaling, forward_operator, clip_x0_mean
+        self.posthoc, self.lam, self.recon_mse = pigdm_posthoc_scaling, diffpir_lambda, recon_mse
+        self.out_sums = []
+
+    def _forward(self, x):  # forward(noiseless=True) without touching the cached pre_calculated of the measurement
+        op = self.op
+        if op.name in ("gaussian_blur", "motion_blur"):
+            FB = op.pre_calculated[0]
+            return torch.fft.ifft2(FB * torch.fft.fft2(x)).real
+        if op.name == "super_resolution":
+            return resizer_apply(x, 1 / op.scale_factor)
+        return x * op.mask
+
+    def __call__(self, x_t, net, y, sigma):
+        sigma = torch.as_tensor(sigma, dtype=torch.float64)
+        x_t = x_t.detach().requires_grad_()
+        x0, _ = net(x_t, sigma)
+        s2 = sigma.pow(2)
+        if self.kind == "dps":
+            norm = torch.linalg.norm(y - self._forward(x0))
+            g = -torch.autograd.grad(norm, x_t)[0] * self.cond_scaling
+            out = x0 + g * s2
+        elif self.kind == "diffpir":
+            var = s2 / self.lam
+            out = x0 + analytic_mat(self.op, y, x0.detach(), var) * var
+        else:
+            if self.kind == "pigdm_videodiff_schedule":
+                var = s2
+            elif self.kind == "peng_analytic" and float(sigma) < 0.2:
+                var = self.recon_mse["mse_list"][(self.recon_mse["sigmas"] - sigma).abs().argmin()]
+            else:
+                var = s2 / (1 + s2)
+            mat = analytic_mat(self.op, y, x0.detach(), var)
+            scale = (var if (self.kind == "pigdm" and self.posthoc) else 1) * self.cond_scaling
+            g = torch.autograd.grad((mat.detach() * x0).sum(), x_t)[0] * scale
+            out = x0 + g * s2
+        out = out.detach()
+        self.out_sums.append(float(out.double().sum()))
+        return out.clip(-1, 1) if self.clip else out
+
+
 def conditional_sampler(net, noise, y, operator, num_steps=30, sigma_min=0.002, sigma_max=80.0, rho=7.0,
                         solver="heun", mechanism_factory=None):
     """Euler/Heun loop.  `y` (the measurement) and `noise` are inputs; returns (x_final f64, mechanism)."""

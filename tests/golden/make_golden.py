@@ -430,9 +430,78 @@ def gold_traj():
     save("trajectories", **out)
 
 
+# ------------------------------------------------------------------ 7. scalar-variance baselines
+BASELINE_CASES = [
+    ("pigdm_gb", "pigdm", "gaussian_blur", "heun", 10, {}),
+    ("pigdm_sr_posthoc", "pigdm", "super_resolution", "heun", 10, {"pigdm_posthoc_scaling": True}),
+    ("pigdmvid_ip", "pigdm_videodiff_schedule", "inpainting", "euler", 12, {}),
+    ("dps_gb", "dps", "gaussian_blur", "heun", 10, {"cond_scaling": 0.5}),
+    ("dps_sr", "dps", "super_resolution", "euler", 12, {"cond_scaling": 0.5}),
+    ("diffpir_mb", "diffpir", "motion_blur", "heun", 10, {"diffpir_lambda": 7.0}),
+    ("peng_analytic_gb", "peng_analytic", "gaussian_blur", "heun", 10, {}),
+]
+
+
+def gold_baselines():
+    """DPS / PiGDM / PiGDM (video-diffusion schedule) / DiffPIR / Peng-analytic through the reference's own
+    conditional_sampler on the small UNet: final image and the per-call sum of the returned x0 estimate."""
+    size = 64
+    net = ref_net(SMALL_A, 11)
+    base = dict(cond_scaling=1.0, clip_x0_mean=False, pigdm_posthoc_scaling=False, max_vector_count=100000,
+                dataset_path="unused/", image_base_covariance="dct_diagonal", pca_component_count=10,
+                denoiser_mean_error_threshold=0.2, use_analytical_score_time_update=True, project_to_diagonal=False,
+                space_step_update_threshold=10.0, space_step_update_lower_threshold=1.0, max_rtol=1.0,
+                do_space_updates=True, use_analytic_var_at_end=False, solver_type="customcuda", use_rtol_func=False,
+                diffpir_lambda=10.0)
+    orig_get_op, orig_choose = ref_gc.get_operator, ref_gc.choose_conditioning_mechanism
+    holder, sums = {}, []
+
+    def rec_get_op(**kw):
+        holder["op"] = orig_get_op(**kw)
+        return holder["op"]
+
+    def recording(cls):
+        def x0_mean_update(self, x_t, model, y, sigma):
+            out = cls.x0_mean_update(self, x_t, model, y, sigma)
+            sums.append(float(out.detach().double().sum()))
+            return out
+        return type("Rec" + cls.__name__, (cls,), {"x0_mean_update": x0_mean_update})
+
+    ref_gc.get_operator = rec_get_op
+    ref_gc.choose_conditioning_mechanism = lambda name: recording(orig_choose(name))
+    out = {"cfg": cfg_dict(SMALL_A), "unet_seed": 11}
+    try:
+        for ci, (tag, mech, opname, solver, nsteps, over) in enumerate(BASELINE_CASES):
+            x0 = smooth_image(size, 140 + ci)
+            noise = randn((1, 3, size, size), 150 + ci, torch.float32)
+            op_kw = dict(name=opname, device=torch.device("cpu"), sigma_s=0.1, kernel_size=61, intensity=1.0,
+                         scale_factor=4, in_shape=(1, 3, size, size),
+                         mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
+                                   "mask_prob_range": (0.6, 0.8), "image_size": size})
+            sums.clear()
+            np.random.seed(160 + ci)
+            torch.manual_seed(160 + ci)
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                x_final, _x_all, y = ref_gc.conditional_sampler(
+                    net, noise, x0.clone(), op_kw, {}, num_steps=nsteps, sigma_min=0.002, sigma_max=80, rho=7,
+                    solver=solver, **{**base, "conditioning_mechanism": mech, **over})
+            p = tag + "__"
+            out.update({p + "seeds": np.array([140 + ci, 150 + ci]), p + "y": y, p + "x_final": x_final,
+                        p + "mech": np.array(mech), p + "op": np.array(opname), p + "solver": np.array(solver),
+                        p + "num_steps": nsteps, p + "over": np.array(repr(over)), p + "out_sum": np.array(sums)})
+            if opname == "inpainting":
+                out[p + "mask"] = holder["op"].mask[:, :1].to(torch.uint8)
+            print(tag, "calls", len(sums), "final range", float(x_final.min()), float(x_final.max()))
+    finally:
+        ref_gc.get_operator, ref_gc.choose_conditioning_mechanism = orig_get_op, orig_choose
+    save("baselines", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sigma", "unet", "cov", "ops", "solver", "traj"]
     torch.set_num_threads(8)
     for w in which:
         {"sigma": gold_sigma, "unet": gold_unet, "cov": gold_cov, "ops": gold_ops, "solver": gold_solver,
-         "traj": gold_traj, "dense": gold_dense}[w]()
+         "traj": gold_traj, "dense": gold_dense, "baselines": gold_baselines}[w]()

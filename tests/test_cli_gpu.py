@@ -29,3 +29,22 @@ def test_cli_two_images(tmp_path):
     arr = np.asarray(PIL.Image.open(out / "images" / "000000_000000.png"))
     assert arr.shape == (256, 256, 3) and arr.std() > 0
     assert "PSNR" in open(out / "results.txt").read()
+
+
+def test_cli_comparison_method(tmp_path):
+    """--conditioning_mechanism=pigdm runs through the same CLI (per-image sampler) and writes PSNR / SSIM."""
+    import PIL.Image
+    sys.path.insert(0, ROOT)
+    from bench import smooth_images
+    import generate_conditional as gc
+    data = tmp_path / "data"
+    data.mkdir()
+    PIL.Image.fromarray(smooth_images(1, 256, 9)[0].permute(1, 2, 0).numpy(), "RGB").save(data / "img00000000.png")
+    out = tmp_path / "out"
+    gc.main([f"--outdir={out}", f"--dataset_path={data}", "--synthetic_weights=ffhq", "--num_steps=3", "--total_images=1",
+             "--max_batch_size=1", "--operator_name=gaussian_blur", "--solver=euler", "--conditioning_mechanism=pigdm"])
+    txt = open(out / "results.txt").read()
+    assert "PSNR" in txt and "SSIM" in txt
+    with pytest.raises(NotImplementedError):
+        gc.main([f"--outdir={out}", f"--dataset_path={data}", "--synthetic_weights=ffhq", "--num_steps=3",
+                 "--total_images=1", "--conditioning_mechanism=tmpd"])

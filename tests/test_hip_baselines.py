@@ -1,0 +1,95 @@
+"""The scalar-variance comparison methods (DPS, PiGDM, PiGDM video-diffusion schedule, DiffPIR, Peng-analytic;
+conditioning_mechanisms.py:52-188) on the HIP operator / UNet-VJP kernels.
+
+The oracle's restatement of each method is pinned to whole trajectories recorded from the reference's
+conditional_sampler (tests/test_oracle_golden.py::test_baseline_trajectory, tests/golden/baselines.npz).  With the
+seeded random UNet these trajectories are not contractive (PiGDM at sigma = 80 multiplies the UNet's VJP by 6400), so
+a free-running comparison across devices is ill-posed for some of them; the HIP path is therefore held to the oracle
+call by call on the oracle's own states (teacher forcing), and free-running where the golden final image is reproduced."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import inputs
+from test_oracle_golden import BASELINE_TAGS, _mk_op, baseline_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+# each case costs ~12 s of CPU-oracle UNet time; three of the seven run only with FH_FULL_TESTS=1
+TF_BASELINE_TAGS = BASELINE_TAGS if os.environ.get("FH_FULL_TESTS") == "1" else ["pigdm_gb", "dps_sr", "diffpir_mb",
+                                                                                 "peng_analytic_gb"]
+
+
+@pytest.mark.parametrize("tag", TF_BASELINE_TAGS)
+def test_baseline_calls_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
+    from oracle import fh_oracle as fo
+    from oracle import unet_oracle as uo
+    from free_hunch_amd.conditioning_mechanisms import choose_conditioning_mechanism
+    from test_hip_parity import _hip_net, _hip_op
+    g = gold("baselines")
+    c = baseline_inputs(g, tag)
+    cfg = inputs.SMALL_A
+    onet = fo.LinearPrecond(uo.OracleUNet(cfg, uo.seeded_state(cfg, int(g["unet_seed"]))))
+    oop = _mk_op(c["opname"], 64, g, c["p"])
+    if c["opname"] != "inpainting":
+        oop.forward(c["x0"].clone())
+    recon = torch.load(os.path.join(ROOT, "free-hunch_amd", "data", "recon_mse.pt"), weights_only=True)
+    calls = []
+
+    class Rec(fo.OracleBaseline):
+        def __call__(self, x_t, net, y, sigma):
+            out = super().__call__(x_t, net, y, sigma)
+            calls.append((x_t.detach().clone(), float(sigma), out.detach().clone()))
+            return out
+
+    fac = lambda op_, v0, d: Rec(c["mech"], c["over"].get("cond_scaling", 1.0), op_, False,
+                                 pigdm_posthoc_scaling=c["over"].get("pigdm_posthoc_scaling", False),
+                                 diffpir_lambda=c["over"].get("diffpir_lambda", 10.0), recon_mse=recon)
+    x_or, _ = fo.conditional_sampler(onet, c["noise"], c["y"], oop, num_steps=c["nsteps"], solver=c["solver"],
+                                     mechanism_factory=fac)
+    # (on the build container this oracle run reproduces the reference's recording - test_oracle_golden.py; on another
+    # CPU the non-contractive cases drift, exactly like the reference itself, so it is not re-asserted here)
+
+    net = _hip_net(g, dev, "hip")
+    mask = torch.from_numpy(g[c["p"] + "mask"]).float().repeat(1, 3, 1, 1) if c["opname"] == "inpainting" else None
+    op = _hip_op(c["opname"], 64, dev, mask)
+    mech = choose_conditioning_mechanism(c["mech"])(
+        c["over"].get("cond_scaling", 1.0), op, False, init_denoiser_variance=1, init_noise_variance=80.0 ** 2,
+        data_dim=3 * 64 * 64, pigdm_posthoc_scaling=c["over"].get("pigdm_posthoc_scaling", False), max_rtol=1.0,
+        diffpir_lambda=c["over"].get("diffpir_lambda", 10.0))
+    y = c["y"].to(dev)
+    worst = 0.0
+    for x_t, sigma, ref in calls:
+        out = mech(x_t.to(dev), net, y, torch.tensor(sigma, dtype=torch.float64, device=dev)).detach().cpu()
+        err = float((out - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        worst = max(worst, err)
+    # the float32 UNet (HIP kernels vs CPU) differs by ~1e-5 relative; the methods scale its VJP by up to sigma^2 = 6400
+    assert worst < 5e-4, worst
+
+
+@pytest.mark.parametrize("tag", ["pigdmvid_ip", "dps_gb", "dps_sr", "diffpir_mb"])
+def test_baseline_trajectory_vs_reference_golden(dev, gold, tag, tmp_path):
+    """Free-running on the device, final image within the north-star 1e-3 of the reference's recording."""
+    from free_hunch_amd.sampler import conditional_sampler
+    from test_hip_parity import _base_kwargs, _hip_net, _hip_op
+    g = gold("baselines")
+    c = baseline_inputs(g, tag)
+    net = _hip_net(g, dev, "hip")
+    mask = torch.from_numpy(g[c["p"] + "mask"]).float().repeat(1, 3, 1, 1) if c["opname"] == "inpainting" else None
+    op = _hip_op(c["opname"], 64, dev, mask)
+    kw = _base_kwargs(tmp_path, {"conditioning_mechanism": c["mech"], "diffpir_lambda": 10.0, "pigdm_posthoc_scaling": False,
+                                 **c["over"]})
+    x, _all, _y = conditional_sampler(net, c["noise"].to(dev), None, None, num_steps=c["nsteps"], sigma_min=0.002,
+                                      sigma_max=80, rho=7, solver=c["solver"], measurement=c["y"].to(dev), operator=op, **kw)
+    ref = torch.from_numpy(g[c["p"] + "x_final"])
+    assert float((x.detach().cpu() - ref).abs().max()) < 1e-3

@@ -295,3 +295,41 @@ def test_dense_helpers_vs_reference(gold, tag, seed, bs, d):
     case = inputs.dense_case(seed, bs, d)
     tu, su = oracle_dense_updates()
     check_dense_chain(gold, inputs.dense_chain(case, tu, su), tag, d, inputs.randn((bs, d), 3000 + seed), 1e-9)
+
+
+# ---------------------------------------------------------------- scalar-variance comparison methods
+BASELINE_TAGS = ["pigdm_gb", "pigdm_sr_posthoc", "pigdmvid_ip", "dps_gb", "dps_sr", "diffpir_mb", "peng_analytic_gb"]
+
+
+def baseline_inputs(g, tag):
+    p = tag + "__"
+    over = eval(str(g[p + "over"]))
+    s_img, s_noise = (int(v) for v in g[p + "seeds"])
+    return dict(p=p, over=over, mech=str(g[p + "mech"]), opname=str(g[p + "op"]), solver=str(g[p + "solver"]),
+                nsteps=int(g[p + "num_steps"]), x0=inputs.smooth_image(64, s_img),
+                noise=inputs.randn((1, 3, 64, 64), s_noise, torch.float32), y=T(g[p + "y"]))
+
+
+@pytest.mark.parametrize("tag", BASELINE_TAGS)
+def test_baseline_trajectory(gold, tag):
+    """DPS / PiGDM / DiffPIR / Peng-analytic restated in the oracle against whole trajectories recorded from the
+    reference's conditional_sampler (tests/golden/baselines.npz): per-call output sums and the final image."""
+    import os
+    g = gold("baselines")
+    c = baseline_inputs(g, tag)
+    cfg = inputs.SMALL_A
+    net = fo.LinearPrecond(uo.OracleUNet(cfg, uo.seeded_state(cfg, int(g["unet_seed"]))))
+    op = _mk_op(c["opname"], 64, g, c["p"])
+    if c["opname"] != "inpainting":
+        op.forward(c["x0"].clone())
+    recon = torch.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "free-hunch_amd", "data",
+                                    "recon_mse.pt"), weights_only=True)
+    fac = lambda op_, v0, d: fo.OracleBaseline(c["mech"], c["over"].get("cond_scaling", 1.0), op_, False,
+                                               pigdm_posthoc_scaling=c["over"].get("pigdm_posthoc_scaling", False),
+                                               diffpir_lambda=c["over"].get("diffpir_lambda", 10.0), recon_mse=recon)
+    x, mech = fo.conditional_sampler(net, c["noise"], c["y"], op, num_steps=c["nsteps"], solver=c["solver"],
+                                     mechanism_factory=fac)
+    ref_sums = g[c["p"] + "out_sum"]
+    assert len(mech.out_sums) == len(ref_sums)
+    assert np.allclose(mech.out_sums, ref_sums, rtol=1e-5, atol=1e-3 * 64 * 64 * 3 * 1e-3)
+    assert maxabs(x, g[c["p"] + "x_final"]) < 1e-4
