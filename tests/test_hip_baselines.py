@@ -25,9 +25,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-# each case costs ~12 s of CPU-oracle UNet time; three of the seven run only with FH_FULL_TESTS=1
-TF_BASELINE_TAGS = BASELINE_TAGS if os.environ.get("FH_FULL_TESTS") == "1" else ["pigdm_gb", "dps_sr", "diffpir_mb",
-                                                                                 "peng_analytic_gb"]
+# each case costs ~12 s of CPU-oracle UNet time; four of the seven run only with FH_FULL_TESTS=1
+TF_BASELINE_TAGS = BASELINE_TAGS if os.environ.get("FH_FULL_TESTS") == "1" else ["pigdm_gb", "dps_sr", "peng_analytic_gb"]
 
 
 @pytest.mark.parametrize("tag", TF_BASELINE_TAGS)
