@@ -15,6 +15,7 @@
 // and B: lane half h supplies k = 4h + s at step s).  Global loads for chunk c+1 are issued before the MFMAs
 // of chunk c and written to the other LDS buffer afterwards: one barrier per chunk.
 #include "fh_common.h"
+#include <stdlib.h>
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
@@ -372,6 +373,188 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
           float v = acc[i][j][r] + bv;
           if (a.res != nullptr && a.ksplit == 1) v += a.res[row * a.Cout + co];
           dst[row * a.Cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-reuse form of k_conv_x6 for 3x3 / stride 1 / pad 1 layers whose 128-pixel tiles are whole row segments (W % 128 == 0,
+// or W = 64 / 32 with the tile spanning 2 / 4 full rows): the 256^2 ... 32^2 levels of the UNet.  The three taps of a kernel row read the same
+// input pixels shifted by one, so the activation tile is staged ONCE per (channel chunk, kernel row) with a one-pixel halo
+// on each side of every row segment (130 ... 136 pixels) and the kx = 0, 1, 2 products read it at row offsets 0, 1, 2: global loads, bf16 splits and
+// LDS writes of the activation operand drop 3x; only the weight tile changes per tap.  Same tile shape as the generic
+// kernel (128 pixels x 128 channels, 8 waves of 64 x 32), same fused epilogue, K order (channel chunk, ky, kx).
+// ------------------------------------------------------------------------------------------------
+template <int SEGW>  // pixels per row segment of the tile: 128 (W % 128 == 0), 64 (W == 64), 32 (W == 32)
+__global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
+  constexpr int MI = 2, NI = 1, WN = 4, T = 512;
+  constexpr int NSEG = 128 / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
+  constexpr int BM = 128, BN = 128, AR = NSEG * SP;
+  constexpr int IA = (AR * 8 + T - 1) / T;  // float4 items per thread for the activation tile (1040 items)
+  constexpr int IB = 3 * BN * 4 / T;        // 16-byte items per thread for the weight tile
+  __shared__ __align__(16) __bf16 As[3][AR][kXLd];
+  __shared__ __align__(16) __bf16 Bs[3][BN][kXLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
+  const int lr = lane & 31, lh = lane >> 5;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int cpt = a.Cin / kBK;
+  const int nchunks = cpt * 9;
+  // the tile is NSEG consecutive row segments of one image: rows py .. py + NSEG - 1, columns px0 .. px0 + SEGW - 1
+  const int pn = (int)(m0 / ((int64_t)a.H * a.W));
+  const int rem = (int)(m0 % ((int64_t)a.H * a.W));
+  const int py = rem / a.W, px0 = rem % a.W;
+
+  int a_row[IA], a_seg[IA], a_gx[IA];
+  bool a_in[IA];
+  const int a_c4 = (tid & 7) * 4;
+#pragma unroll
+  for (int e = 0; e < IA; ++e) {
+    const int idx = e * T + tid;
+    a_row[e] = idx >> 3;
+    a_seg[e] = a_row[e] / SP;
+    a_gx[e] = px0 - 1 + a_row[e] % SP;
+    a_in[e] = idx < AR * 8 && a_gx[e] >= 0 && a_gx[e] < a.W;
+    if (idx >= AR * 8) a_row[e] = -1;
+  }
+  const int64_t wplane = (int64_t)9 * cpt * a.Cout * kBK;
+  int b_pl[IB], b_row[IB];
+  bool b_ok[IB];
+  const int b_part = (tid & 3) * 8;
+#pragma unroll
+  for (int e = 0; e < IB; ++e) {
+    const int idx = e * T + tid;
+    b_pl[e] = idx / (BN * 4);
+    b_row[e] = (idx % (BN * 4)) >> 2;
+    b_ok[e] = n0 + b_row[e] < a.Cout;
+  }
+  float4 ra_reg[IA];
+  bf16x8_t rb_reg[IB];
+  auto load_a = [&](int cc, int ky) {
+    const float* base = a.in + (int64_t)pn * a.H * a.W * a.Cin + cc * kBK + a_c4;
+#pragma unroll
+    for (int e = 0; e < IA; ++e) {
+      const int gy = py + a_seg[e] + ky - 1;
+      const bool ok = a_in[e] && gy >= 0 && gy < a.H;
+      ra_reg[e] = ok ? *reinterpret_cast<const float4*>(base + ((int64_t)gy * a.W + a_gx[e]) * a.Cin)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto load_b = [&](int cc, int tap) {
+    const __bf16* wbase = a.wx + ((int64_t)tap * cpt + cc) * a.Cout * kBK;
+#pragma unroll
+    for (int e = 0; e < IB; ++e) {
+      bf16x8_t z;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) z[q] = (__bf16)0.f;
+      const __bf16* src = wbase + b_pl[e] * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
+      rb_reg[e] = b_ok[e] ? *reinterpret_cast<const bf16x8_t*>(src) : z;
+    }
+  };
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  auto store_a = [&]() {
+#pragma unroll
+    for (int e = 0; e < IA; ++e) {
+      if (a_row[e] < 0) continue;
+      bf16x4_t h4, m4, l4;
+      const float4 v = ra_reg[e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+        __bf16 h, m, l;
+        split3(x, h, m, l);
+        h4[q] = h, m4[q] = m, l4[q] = l;
+      }
+      *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
+      *reinterpret_cast<bf16x4_t*>(&As[1][a_row[e]][a_c4]) = m4;
+      *reinterpret_cast<bf16x4_t*>(&As[2][a_row[e]][a_c4]) = l4;
+    }
+  };
+  auto store_b = [&]() {
+#pragma unroll
+    for (int e = 0; e < IB; ++e) *reinterpret_cast<bf16x8_t*>(&Bs[b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
+  };
+  float16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int arow[MI];  // staged row of this lane's pixel: pixel j of the tile sits at j + 2 * (j / SEGW) + 1, tap kx at - 1 + kx
+#pragma unroll
+  for (int i = 0; i < MI; ++i) arow[i] = wm + i * 32 + lr + 2 * ((wm + i * 32 + lr) / SEGW);
+  auto compute = [&](int kx) {
+#pragma unroll
+    for (int ks = 0; ks < kBK / 16; ++ks) {
+      const int ko = ks * 16 + 8 * lh;
+      bf16x8_t af[3][MI], bfr[3][NI];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][arow[i] + kx][ko]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[p][wn + j * 32 + lr][ko]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          float16_t t = acc[i][j];
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);
+          acc[i][j] = t;
+        }
+    }
+  };
+  // chunk c = (cc * 3 + ky) * 3 + kx
+  load_a(0, 0);
+  load_b(0, 0);
+  store_a();
+  store_b();
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int kx = c % 3;
+    const int nx = c + 1;
+    const bool more = nx < nchunks;
+    const bool new_row = more && (nx % 3 == 0);
+    if (more) {
+      const int ncc = nx / 9, nky = (nx / 3) % 3, nkx = nx % 3;
+      load_b(ncc, nky * 3 + nkx);
+      if (new_row) load_a(ncc, nky);
+    }
+    compute(kx);
+    __syncthreads();
+    if (more) {
+      store_b();
+      if (new_row) store_a();
+      __syncthreads();
+    }
+  }
+  const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int co = n0 + wn + j * 32 + lr;
+    if (co >= a.Cout) continue;
+    const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (a.res != nullptr) v += a.res[row * a.Cout + co];
+          a.out[row * a.Cout + co] = v;
         }
       }
     }
@@ -1091,7 +1274,16 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
   // 128 x 128 tiles run as 8 waves (2 x 4, wave tile 64 x 32: 102 VGPRs, 4 waves per SIMD over two workgroups per CU)
   const int64_t b128 = ((M + 127) / 128) * ((Cout + 127) / 128);
   if (ksplit == 1 && Cout > 64 && b128 >= 384) {
-    hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+    static const int no_reuse = getenv("FH_X6_NOREUSE") != nullptr;
+    const bool r3 = !no_reuse && KH == 3 && KW == 3 && pad == 1 && stride == 1 && M % 128 == 0;
+    if (r3 && W % 128 == 0)
+      hipLaunchKernelGGL(k_conv_x6r<128>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+    else if (r3 && W == 64 && H % 2 == 0)
+      hipLaunchKernelGGL(k_conv_x6r<64>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+    else if (r3 && W == 32 && H % 4 == 0)
+      hipLaunchKernelGGL(k_conv_x6r<32>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
     hipLaunchKernelGGL((k_conv_x6<1, 2, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {

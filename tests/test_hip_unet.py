@@ -191,7 +191,8 @@ def test_conv_winograd_vs_torch(dev, shape):
 
 @pytest.mark.parametrize("shape", [(1, 64, 64, 128, 128, 3, 1), (2, 16, 32, 64, 96, 3, 1), (1, 256, 256, 32, 128, 3, 1),
                                    (1, 9, 14, 32, 6, 3, 1), (3, 8, 8, 160, 64, 3, 1), (2, 32, 32, 256, 320, 1, 1),
-                                   (1, 33, 31, 64, 130, 3, 2), (8, 64, 64, 128, 256, 3, 1)])
+                                   (1, 33, 31, 64, 130, 3, 2), (8, 64, 64, 128, 256, 3, 1), (2, 128, 128, 64, 160, 3, 1),
+                                   (4, 128, 256, 96, 128, 3, 1), (16, 32, 32, 64, 384, 3, 1), (9, 64, 64, 32, 256, 3, 1)])
 def test_conv_split_bf16_vs_float64(dev, shape):
     """fh_conv2d_x6_nhwc (exact 3-way bf16 split, six products) against float64: the error must be that of an fp32
     dot product - checked relative to the fp32-MFMA kernel on the same data (<= 1.5x its error, and < 2e-6 of scale)."""
