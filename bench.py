@@ -199,7 +199,7 @@ def roofline_dense_cov_apply(device, d=12288, iters=30):
 
 def roofline_conv_mfma(device, iters=20):
     """The dominant UNet kernel: 3x3 conv 128 -> 128 on 8 x 256 x 256 NHWC (the most frequent FFHQ layer), events on
-    the launch stream.  k_conv_x6 computes the fp32 convolution with six bf16 MFMAs per K = 16 block (exact 3-way
+    the launch stream.  k_conv_x6r computes the fp32 convolution with six bf16 MFMAs per K = 16 block (exact 3-way
     operand split), so `achieved` counts the EXECUTED bf16 matrix FLOPs (6 x the algorithmic fp32 FLOPs) against the
     dense bf16 peak (2.5 PFLOP/s, MI355X_MICROARCH.md); `fp32_equivalent_tflops` is the algorithmic rate, to be read
     against the 157.3 TFLOP/s fp32 matrix peak that the fp32-MFMA kernel (k_conv_igemm, also timed) is bound by."""
@@ -233,7 +233,7 @@ def roofline_conv_mfma(device, iters=20):
     t6, t32 = timed(f_x6), timed(f_32)
     flops = 2.0 * N * H * W * Ci * Co * k * k
     ach = 6 * flops / t6 / 1e12
-    return {"bound": "mfma", "kernel": "k_conv_x6<2,1,2,4> 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
+    return {"bound": "mfma", "kernel": "k_conv_x6r<128> 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
             "flops_per_launch": 6 * flops, "us_per_launch": round(t6 * 1e6, 1),
             "fp32_equivalent_tflops": round(flops / t6 / 1e12, 1),
