@@ -64,6 +64,9 @@ _SIGS = {
     "fh_conv2d_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_x6_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
+    "fh_groupnorm_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "fh_conv2d_x6_norm_supported": ([C.c_int] * 5, C.c_int),
+    "fh_conv2d_x6_norm_nhwc": ([c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_conv3x3_thin_nhwc": ([c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_conv3x3_wino_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_bgemm_f32": ([c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_int64] * 6 + [C.c_float, C.c_void_p], C.c_int),

@@ -190,6 +190,8 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int kXLd = kBK + 8;  // bf16 row stride (80 B)
 
 struct ConvArgsX {
+  const float* ab;    // [N][2][Cin] GroupNorm affine table (A plane, B plane) of the fused-input form, else null
+  int act;            // fused input: 1 = SiLU after the affine
   const float* in;
   const __bf16* wx;   // [3 planes][taps][Cin/32][Cout][32]
   const float* bias;
@@ -199,6 +201,8 @@ struct ConvArgsX {
   int ksplit;
   float* ws;
 };
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -387,7 +391,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // LDS writes of the activation operand drop 3x; only the weight tile changes per tap.  Same tile shape as the generic
 // kernel (128 pixels x 128 channels, 8 waves of 64 x 32), same fused epilogue, K order (channel chunk, ky, kx).
 // ------------------------------------------------------------------------------------------------
-template <int SEGW>  // pixels per row segment of the tile: 128 (W % 128 == 0), 64 (W == 64), 32 (W == 32)
+// NORM: the input is GroupNorm(+scale/shift)(+SiLU) of `in`, applied while the tile is staged: y = act(A[n][c] x + B[n][c])
+// with the same fmaf / SiLU as k_gn_stream (bit-identical to the two-kernel path); padding pixels stay exactly zero.  The
+// separate apply pass (one read + one write of the activation) and the normalised tensor itself disappear; the affine is
+// re-evaluated 3 x (Cout / 128) times per element, which the MFMAs hide.
+template <int SEGW, bool NORM = false>  // SEGW: pixels per row segment of the tile: 128 (W % 128 == 0), 64, 32
 __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
   constexpr int MI = 2, NI = 1, WN = 4, T = 512;
   constexpr int NSEG = 128 / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
@@ -434,13 +442,21 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
     b_ok[e] = n0 + b_row[e] < a.Cout;
   }
   float4 ra_reg[IA];
+  bool ra_ok[IA];
+  float4 tA = make_float4(1.f, 1.f, 1.f, 1.f), tB = make_float4(0.f, 0.f, 0.f, 0.f);
   bf16x8_t rb_reg[IB];
   auto load_a = [&](int cc, int ky) {
+    if (NORM) {
+      const float* t = a.ab + (int64_t)pn * 2 * a.Cin + cc * kBK + a_c4;
+      tA = *reinterpret_cast<const float4*>(t);
+      tB = *reinterpret_cast<const float4*>(t + a.Cin);
+    }
     const float* base = a.in + (int64_t)pn * a.H * a.W * a.Cin + cc * kBK + a_c4;
 #pragma unroll
     for (int e = 0; e < IA; ++e) {
       const int gy = py + a_seg[e] + ky - 1;
       const bool ok = a_in[e] && gy >= 0 && gy < a.H;
+      ra_ok[e] = ok;
       ra_reg[e] = ok ? *reinterpret_cast<const float4*>(base + ((int64_t)gy * a.W + a_gx[e]) * a.Cin)
                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -465,7 +481,13 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
       const float4 v = ra_reg[e];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+        float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+        if (NORM) {
+          const float ta = q == 0 ? tA.x : q == 1 ? tA.y : q == 2 ? tA.z : tA.w;
+          const float tb = q == 0 ? tB.x : q == 1 ? tB.y : q == 2 ? tB.z : tB.w;
+          const float t = fmaf(x, ta, tb);
+          x = ra_ok[e] ? (a.act ? silu_f(t) : t) : 0.f;
+        }
         __bf16 h, m, l;
         split3(x, h, m, l);
         h4[q] = h, m4[q] = m, l4[q] = l;
@@ -1010,7 +1032,6 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ 
   }
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
 
 // Streaming passes.  Workgroup = (image n, chunk of kGnChunk pixels); a thread owns one float4 of channels for its
 // whole pixel loop, so everything that depends on (n, channel) only - mean, rstd, gamma, beta, scale, shift, the
@@ -1263,6 +1284,7 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
     return FH_EINVAL;
   if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
   ConvArgsX a;
+  a.ab = nullptr, a.act = 0;
   a.in = in, a.wx = (const __bf16*)wx, a.bias = bias, a.res = res, a.out = out;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
   a.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -1294,6 +1316,62 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
     hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_for(total)), dim3(256), 0, st, (const float*)ws, bias, res, out, total,
                        Cout, ksplit);
   }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// A[n][c] = rstd * gamma * (1 + scale), B[n][c] = (beta - mean * rstd * gamma) * (1 + scale) + shift: exactly k_gn_stream's
+// per-channel constants, as a table [N][2][C] for the fused-input convolution
+__global__ __launch_bounds__(256) void k_gn_table(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, int ss_stride,
+                                                  float* __restrict__ table, int C) {
+  const int n = blockIdx.x, cg = C / 32;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int64_t si = ((int64_t)n * 32 + c / cg) * 2;
+    const float mean = stats[si], rstd = stats[si + 1];
+    const float sc = scale != nullptr ? 1.f + scale[(int64_t)n * ss_stride + c] : 1.f;
+    const float sh = shift != nullptr ? shift[(int64_t)n * ss_stride + c] : 0.f;
+    const float rg = rstd * gamma[c];
+    table[((int64_t)n * 2 + 0) * C + c] = rg * sc;
+    table[((int64_t)n * 2 + 1) * C + c] = (beta[c] - mean * rg) * sc + sh;
+  }
+}
+
+int fh_groupnorm_table(const float* stats, const float* gamma, const float* beta, const float* scale, const float* shift,
+                       int ss_stride, float* table, int N, int C, void* stream) {
+  if (!stats || !gamma || !beta || !table || N < 1 || C % 32 != 0) return FH_EINVAL;
+  hipLaunchKernelGGL(k_gn_table, dim3(N), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale, shift, ss_stride,
+                     table, C);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// 1 when fh_conv2d_x6_norm_nhwc supports the layer (the row-reuse tiling must apply and fill the chip)
+int fh_conv2d_x6_norm_supported(int N, int H, int W, int Cin, int Cout) {
+  const int64_t M = (int64_t)N * H * W;
+  if (Cin < kBK || Cin % kBK != 0 || Cout <= 64 || M % 128 != 0) return 0;
+  if (((M + 127) / 128) * ((Cout + 127) / 128) < 384) return 0;
+  return (W % 128 == 0) || (W == 64 && H % 2 == 0) || (W == 32 && H % 4 == 0);
+}
+
+int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                           const float* res, float* out, int N, int H, int W, int Cin, int Cout, void* stream) {
+  if (!in || !ab_table || !wx || !out || !fh_conv2d_x6_norm_supported(N, H, W, Cin, Cout)) return FH_EINVAL;
+  ConvArgsX a;
+  a.ab = ab_table, a.act = act;
+  a.in = in, a.wx = (const __bf16*)wx, a.bias = bias, a.res = res, a.out = out;
+  a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = 3, a.KW = 3, a.pad = 1, a.stride = 1;
+  a.Ho = H, a.Wo = W, a.ksplit = 1, a.ws = nullptr;
+  const int64_t M = (int64_t)N * H * W;
+  const dim3 grid((unsigned)(M / 128), (Cout + 127) / 128, 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (W % 128 == 0)
+    hipLaunchKernelGGL((k_conv_x6r<128, true>), grid, dim3(512), 0, st, a);
+  else if (W == 64)
+    hipLaunchKernelGGL((k_conv_x6r<64, true>), grid, dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_conv_x6r<32, true>), grid, dim3(512), 0, st, a);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -164,20 +164,50 @@ class HipOps:
                                            c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_nhwc(dgrad)")
         return out
 
-    def _gn(self, name, x, act, scale=None, shift=None):
+    def _gn_stats(self, x):
         N, H, W, C = x.shape
         stats = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
-        y = torch.empty_like(x)
-        st = _lib.stream()
         scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
-        _lib.check(self.lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, C, st),
-                   "gn_stats")
+        _lib.check(self.lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, C,
+                                               _lib.stream()), "gn_stats")
+        return stats
+
+    def _gn_apply(self, name, x, stats, act, scale=None, shift=None):
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
         ss = 0 if scale is None else scale.stride(0)
         _lib.check(self.lib.fh_groupnorm_apply(
             x.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(), self.P[name + ".bias"].data_ptr(),
             None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss,
-            y.data_ptr(), N, H * W, C, int(act), st), "gn_apply")
-        return y, stats
+            y.data_ptr(), N, H * W, C, int(act), _lib.stream()), "gn_apply")
+        return y
+
+    def _gn(self, name, x, act, scale=None, shift=None):
+        stats = self._gn_stats(x)
+        return self._gn_apply(name, x, stats, act, scale, shift), stats
+
+    def _gn_conv(self, gn_name, conv_name, x, act, scale=None, shift=None, res=None):
+        """conv3x3(act(GroupNorm(x))) - the in_layers / out_layers pattern of a ResBlock.  Where the row-reuse split-bf16
+        kernel applies, the normalisation is folded into its tile staging (fh_conv2d_x6_norm_nhwc): the normalised tensor
+        is never written.  Returns (conv output, GroupNorm statistics)."""
+        c = self.conv[conv_name]
+        N, H, W, Ci = x.shape
+        stats = self._gn_stats(x)
+        if (c.wx_f is not None and c.kh == 3 and c.kw == 3 and Ci == c.ci_p and os.environ.get("FH_GN_FUSE", "1") != "0"
+                and self.lib.fh_conv2d_x6_norm_supported(N, H, W, Ci, c.co)):
+            table = torch.empty(N, 2, Ci, dtype=torch.float32, device=x.device)
+            ss = 0 if scale is None else scale.stride(0)
+            _lib.check(self.lib.fh_groupnorm_table(
+                stats.data_ptr(), self.P[gn_name + ".weight"].data_ptr(), self.P[gn_name + ".bias"].data_ptr(),
+                None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss,
+                table.data_ptr(), N, Ci, _lib.stream()), "gn_table")
+            out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
+            _lib.check(self.lib.fh_conv2d_x6_norm_nhwc(x.data_ptr(), table.data_ptr(), int(act), c.wx_f.data_ptr(),
+                                                       c.b.data_ptr(), None if res is None else res.data_ptr(),
+                                                       out.data_ptr(), N, H, W, Ci, c.co, _lib.stream()),
+                       "fh_conv2d_x6_norm_nhwc")
+            return out, stats
+        return self._conv(conv_name, self._gn_apply(gn_name, x, stats, act, scale, shift), res=res), stats
 
     def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None):
         N, H, W, C = x.shape
@@ -227,26 +257,29 @@ class HipOps:
     # ---------------------------------------------------------------- blocks
     def _res_fwd(self, op, p, x, emb, tape):
         cfg = self.cfg
-        h0, st0 = self._gn(p + ".in_layers.0", x, act=1)
-        xs = x
-        if op == "res_down":
-            h0, xs = self._resample(h0, 0), self._resample(x, 0)
-        elif op == "res_up":
-            h0, xs = self._resample(h0, 2), self._resample(x, 2)
         e = self.emb_out(p, emb)  # [N, Co] or [N, 2 Co]
         co = self.conv[p + ".in_layers.2"].co
+        xs = x
+        h0 = None
+        if op != "res":  # the resampling sits between the normalisation and the convolution (resblock_updown)
+            h0, st0 = self._gn(p + ".in_layers.0", x, act=1)
+            mode = 0 if op == "res_down" else 2
+            h0, xs = self._resample(h0, mode), self._resample(x, mode)
         if cfg.use_scale_shift_norm:
-            h1 = self._conv(p + ".in_layers.2", h0)
+            if h0 is None:
+                h1, st0 = self._gn_conv(p + ".in_layers.0", p + ".in_layers.2", x, act=1)
+            else:
+                h1 = self._conv(p + ".in_layers.2", h0)
             scale, shift = e[:, :co], e[:, co:]
-            h2, st1 = self._gn(p + ".out_layers.0", h1, act=1, scale=scale, shift=shift)
         else:
             if e.shape[0] != 1 and not bool((e == e[:1]).all()):
                 raise NotImplementedError("per-sample timestep embeddings without scale-shift norm")
+            if h0 is None:
+                h0, st0 = self._gn(p + ".in_layers.0", x, act=1)
             h1 = self._conv(p + ".in_layers.2", h0, bias_override=(self.conv[p + ".in_layers.2"].b + e[0]).contiguous())
             scale = shift = None
-            h2, st1 = self._gn(p + ".out_layers.0", h1, act=1)
         skip = self._conv(p + ".skip_connection", xs) if (p + ".skip_connection") in self.conv else xs
-        out = self._conv(p + ".out_layers.3", h2, res=skip)
+        out, st1 = self._gn_conv(p + ".out_layers.0", p + ".out_layers.3", h1, act=1, scale=scale, shift=shift, res=skip)
         tape.append(("res", op, p, x, st0, h1, st1, scale, shift))
         return out
 

@@ -199,6 +199,17 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
                       int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
                       void* stream);
 
+/* GroupNorm(+scale/shift)(+SiLU) fused into the convolution that consumes it (openai_unet.py:236-256: in_layers /
+ * out_layers = GroupNorm32 -> SiLU -> conv3x3):  out = conv3x3(act(A[n][c] * in + B[n][c])) + bias (+ res), with
+ * fh_groupnorm_table building [N][2][C] = (A, B) from the statistics exactly as fh_groupnorm_apply would (same bits).
+ * Only where fh_conv2d_x6_norm_supported() returns 1 (3x3, stride 1, pad 1, row-aligned 128-pixel tiles that fill the
+ * chip); elsewhere the caller runs fh_groupnorm_apply + fh_conv2d_*. */
+int fh_groupnorm_table(const float* stats, const float* gamma, const float* beta, const float* scale, const float* shift,
+                       int ss_stride, float* table, int N, int C, void* stream);
+int fh_conv2d_x6_norm_supported(int N, int H, int W, int Cin, int Cout);
+int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                           const float* res, float* out, int N, int H, int W, int Cin, int Cout, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution with a thin output, Cout <= 8 (the 128 -> 6 output convolution and the
  * 128 -> 3 input gradient of the first one): direct form, w [Cout][9][Cin] as for fh_conv2d_nhwc, Cin % 32 == 0. */
 int fh_conv3x3_thin_nhwc(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,

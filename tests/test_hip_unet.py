@@ -247,6 +247,51 @@ def test_conv_thin_vs_float64(dev, shape):
     assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 256, 64, 128, True), (8, 64, 64, 96, 256, False), (16, 32, 32, 64, 384, True)])
+def test_conv_with_fused_groupnorm_vs_two_kernel_path(dev, shape):
+    """fh_conv2d_x6_norm_nhwc = fh_groupnorm_apply + fh_conv2d_x6_nhwc bit for bit (same affine constants, same SiLU),
+    and both within fp32 accuracy of a float64 GroupNorm -> SiLU -> conv."""
+    from free_hunch_amd.unet_hip import _split3
+    L, lib = _lib()
+    N, H, W, Ci, Co, with_ss = shape
+    assert lib.fh_conv2d_x6_norm_supported(N, H, W, Ci, Co) == 1
+    g = torch.Generator().manual_seed(sum(shape[:5]) + 21)
+    x = (torch.randn(N, H, W, Ci, generator=g) * 1.7 + 0.3).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(Ci, generator=g)).to(dev), (0.1 * torch.randn(Ci, generator=g)).to(dev)
+    ss = (0.3 * torch.randn(N, 2 * Ci, generator=g)).to(dev) if with_ss else None
+    scale, shift = (ss[:, :Ci], ss[:, Ci:]) if with_ss else (None, None)
+    res = torch.randn(N, H, W, Co, generator=g).to(dev)
+    wx = _split3(w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous())
+    st = L.stream()
+    stats = torch.empty(N, 32, 2, device=dev)
+    scratch = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
+    L.check(lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, Ci, st), "stats")
+    sp = lambda t: None if t is None else t.data_ptr()
+    stride = 0 if ss is None else ss.stride(0)
+    y = torch.empty_like(x)
+    L.check(lib.fh_groupnorm_apply(x.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sp(scale), sp(shift),
+                                   stride, y.data_ptr(), N, H * W, Ci, 1, st), "apply")
+    two = torch.empty(N, H, W, Co, device=dev)
+    L.check(lib.fh_conv2d_x6_nhwc(y.data_ptr(), wx.data_ptr(), b.data_ptr(), res.data_ptr(), two.data_ptr(), None, 1, N, H,
+                                  W, Ci, Co, 3, 3, 1, 1, st), "conv")
+    table = torch.empty(N, 2, Ci, device=dev)
+    L.check(lib.fh_groupnorm_table(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sp(scale), sp(shift), stride,
+                                   table.data_ptr(), N, Ci, st), "table")
+    one = torch.full((N, H, W, Co), float("nan"), device=dev)
+    L.check(lib.fh_conv2d_x6_norm_nhwc(x.data_ptr(), table.data_ptr(), 1, wx.data_ptr(), b.data_ptr(), res.data_ptr(),
+                                       one.data_ptr(), N, H, W, Ci, Co, st), "fused")
+    assert torch.equal(one, two)
+    xd = x.double().permute(0, 3, 1, 2)
+    ref = F.group_norm(xd, 32, gamma.double(), beta.double(), eps=1e-5)
+    if with_ss:
+        ref = ref * (1 + scale.double()[:, :, None, None]) + shift.double()[:, :, None, None]
+    ref = F.conv2d(F.silu(ref), w.double(), b.double(), padding=1) + res.double().permute(0, 3, 1, 2)
+    assert rel(one.permute(0, 3, 1, 2), ref) < 2e-5
+    assert lib.fh_conv2d_x6_norm_supported(1, 16, 16, 64, 128) == 0
+
+
 def test_conv_split_bf16_splitk(dev):
     """K-split path of the split-bf16 kernel (small grids): partial sums through the workspace + fixed-order reduce."""
     from free_hunch_amd.unet_hip import _split3
