@@ -371,7 +371,7 @@ def main():
             "metric": f"images/sec (256x256, num_steps={a.num_steps}, FH-{a.solver.capitalize()})",
             "value": round(total_images / elapsed, 5), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy) + f64 covariance/CG", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy)" if os.environ.get("FH_CONV_MODE", "x6") == "x6" else "f32 UNet (fp32 MFMA)") + " + f64 covariance/CG", "data": "synthetic",
             "config": {"workload": f"{a.arch.upper()}-256 arch, {a.operator}, FH low-rank covariance (dct_diagonal), "
                                    f"num_steps={a.num_steps} {a.solver}, batch={a.batch} per GPU",
                        "images_per_step": a.batch * world, "lockstep_groups_per_gpu": a.groups,
