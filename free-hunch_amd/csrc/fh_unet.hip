@@ -395,15 +395,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // with the same fmaf / SiLU as k_gn_stream (bit-identical to the two-kernel path); padding pixels stay exactly zero.  The
 // separate apply pass (one read + one write of the activation) and the normalised tensor itself disappear; the affine is
 // re-evaluated 3 x (Cout / 128) times per element, which the MFMAs hide.
-template <int SEGW, bool NORM = false>  // SEGW: pixels per row segment of the tile: 128 (W % 128 == 0), 64, 32
-__global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
-  constexpr int MI = 2, NI = 1, WN = 4, T = 512;
-  constexpr int NSEG = 128 / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
-  constexpr int BM = 128, BN = 128, AR = NSEG * SP;
+// BM = 256 (16 waves, one workgroup per CU): the kernel is bound by the ~12 B/clk a CU can pull from L2, and per K step it
+// pulls 1.33 B per pixel (fp32, every third tap) but 6 B per output channel (three bf16 planes, every tap): arithmetic
+// intensity 2 BM BN / (1.33 BM + 6 BN) = 35 flop/B at 128 x 128 (-> ~190 TFLOP/s fp32-equivalent, as measured) and 59 at
+// 256 x 128, past the 50 flop/B where the MFMAs at the held clock become the limit.
+template <int SEGW, bool NORM = false, int BM = 128>  // SEGW: pixels per row segment of the tile (W, capped at BM)
+__global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
+  constexpr int MI = 2, NI = 1, WN = 4, T = 4 * BM;
+  constexpr int NSEG = BM / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
+  constexpr int BN = 128, AR = NSEG * SP;
   constexpr int IA = (AR * 8 + T - 1) / T;  // float4 items per thread for the activation tile (1040 items)
-  constexpr int IB = 3 * BN * 4 / T;        // 16-byte items per thread for the weight tile
+  constexpr int IB = (3 * BN * 4 + T - 1) / T;  // 16-byte items per thread for the weight tile (1536 items)
   __shared__ __align__(16) __bf16 As[3][AR][kXLd];
-  __shared__ __align__(16) __bf16 Bs[3][BN][kXLd];
+  constexpr int NB = 1;  // (a second weight buffer in the 256-pixel variant, one barrier per tap, was measured: no gain)
+  __shared__ __align__(16) __bf16 Bs[NB][3][BN][kXLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
   const int lr = lane & 31, lh = lane >> 5;
@@ -437,9 +442,9 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
   for (int e = 0; e < IB; ++e) {
     const int idx = e * T + tid;
-    b_pl[e] = idx / (BN * 4);
+    b_pl[e] = idx < 3 * BN * 4 ? idx / (BN * 4) : -1;
     b_row[e] = (idx % (BN * 4)) >> 2;
-    b_ok[e] = n0 + b_row[e] < a.Cout;
+    b_ok[e] = b_pl[e] >= 0 && n0 + b_row[e] < a.Cout;
   }
   float4 ra_reg[IA];
   bool ra_ok[IA];
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
       bf16x8_t z;
 #pragma unroll
       for (int q = 0; q < 8; ++q) z[q] = (__bf16)0.f;
-      const __bf16* src = wbase + b_pl[e] * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
+      const __bf16* src = wbase + (b_ok[e] ? b_pl[e] : 0) * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
       rb_reg[e] = b_ok[e] ? *reinterpret_cast<const bf16x8_t*>(src) : z;
     }
   };
@@ -497,9 +502,10 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
       *reinterpret_cast<bf16x4_t*>(&As[2][a_row[e]][a_c4]) = l4;
     }
   };
-  auto store_b = [&]() {
+  auto store_b = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < IB; ++e) *reinterpret_cast<bf16x8_t*>(&Bs[b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
+    for (int e = 0; e < IB; ++e)
+      if (b_pl[e] >= 0) *reinterpret_cast<bf16x8_t*>(&Bs[buf][b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
   };
   float16_t acc[MI][NI];
 #pragma unroll
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
   int arow[MI];  // staged row of this lane's pixel: pixel j of the tile sits at j + 2 * (j / SEGW) + 1, tap kx at - 1 + kx
 #pragma unroll
   for (int i = 0; i < MI; ++i) arow[i] = wm + i * 32 + lr + 2 * ((wm + i * 32 + lr) / SEGW);
-  auto compute = [&](int kx) {
+  auto compute = [&](int kx, int bbuf) {
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
       const int ko = ks * 16 + 8 * lh;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][arow[i] + kx][ko]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[p][wn + j * 32 + lr][ko]);
+        for (int j = 0; j < NI; ++j) bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[bbuf][p][wn + j * 32 + lr][ko]);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
   load_a(0, 0);
   load_b(0, 0);
   store_a();
-  store_b();
+  store_b(0);
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const int kx = c % 3;
@@ -554,12 +560,14 @@ __global__ __launch_bounds__(512, 4) void k_conv_x6r(ConvArgsX a) {
       load_b(ncc, nky * 3 + nkx);
       if (new_row) load_a(ncc, nky);
     }
-    compute(kx);
-    __syncthreads();
-    if (more) {
-      store_b();
-      if (new_row) store_a();
+    {
+      compute(kx, 0);
       __syncthreads();
+      if (more) {
+        store_b(0);
+        if (new_row) store_a();
+        __syncthreads();
+      }
     }
   }
   const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
@@ -1298,7 +1306,16 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
   if (ksplit == 1 && Cout > 64 && b128 >= 384) {
     static const int no_reuse = getenv("FH_X6_NOREUSE") != nullptr;
     const bool r3 = !no_reuse && KH == 3 && KW == 3 && pad == 1 && stride == 1 && M % 128 == 0;
-    if (r3 && W % 128 == 0)
+    static const int no_big = getenv("FH_X6_NOBIG") != nullptr;
+    const bool big = r3 && !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
+    const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
+    if (big && W % 256 == 0)
+      hipLaunchKernelGGL((k_conv_x6r<256, false, 256>), gbig, dim3(1024), 0, st, a);
+    else if (big && W == 128 && H % 2 == 0)
+      hipLaunchKernelGGL((k_conv_x6r<128, false, 256>), gbig, dim3(1024), 0, st, a);
+    else if (big && W == 64 && H % 4 == 0)
+      hipLaunchKernelGGL((k_conv_x6r<64, false, 256>), gbig, dim3(1024), 0, st, a);
+    else if (r3 && W % 128 == 0)
       hipLaunchKernelGGL(k_conv_x6r<128>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 64 && H % 2 == 0)
       hipLaunchKernelGGL(k_conv_x6r<64>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
@@ -1366,7 +1383,16 @@ int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, cons
   const int64_t M = (int64_t)N * H * W;
   const dim3 grid((unsigned)(M / 128), (Cout + 127) / 128, 1);
   hipStream_t st = (hipStream_t)stream;
-  if (W % 128 == 0)
+  static const int no_big = getenv("FH_X6_NOBIG") != nullptr;
+  const bool big = !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
+  const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
+  if (big && W % 256 == 0)
+    hipLaunchKernelGGL((k_conv_x6r<256, true, 256>), gbig, dim3(1024), 0, st, a);
+  else if (big && W == 128 && H % 2 == 0)
+    hipLaunchKernelGGL((k_conv_x6r<128, true, 256>), gbig, dim3(1024), 0, st, a);
+  else if (big && W == 64 && H % 4 == 0)
+    hipLaunchKernelGGL((k_conv_x6r<64, true, 256>), gbig, dim3(1024), 0, st, a);
+  else if (W % 128 == 0)
     hipLaunchKernelGGL((k_conv_x6r<128, true>), grid, dim3(512), 0, st, a);
   else if (W == 64)
     hipLaunchKernelGGL((k_conv_x6r<64, true>), grid, dim3(512), 0, st, a);
