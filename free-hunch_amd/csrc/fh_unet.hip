@@ -1323,6 +1323,9 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
       hipLaunchKernelGGL(k_conv_x6r<32>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else
       hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+  } else if (ksplit > 1 && Cout > 64 && b128 * ksplit >= 256 && !getenv("FH_X6_NOBIGSPLIT")) {
+    // small grids: 128 x 128 tiles (21 flop per byte pulled from L2 instead of 12.8) once split-K still fills the chip
+    hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
     hipLaunchKernelGGL((k_conv_x6<1, 2, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
