@@ -189,8 +189,13 @@ def roofline_dense_cov_apply(device, d=12288, iters=30):
     t_r2 = timed(lambda: dense.rank2(A, u, v, c, v, u, c, out=out))
     mv_bytes, r2_bytes = 8 * d * d + 16 * d, 16 * d * d + 32 * d
     ach = mv_bytes / t_mv / 1e9
+    traffic = None  # HBM-side bytes per mat-vec from the committed PMC passes (1.0009 x algorithmic)
+    pmc = os.path.join(ROOT, "profiles", "r01_dense_pmc.json")
+    if d == 12288 and os.path.exists(pmc):
+        with open(pmc) as f_:
+            traffic = json.load(f_).get("traffic_bytes_per_apply_d12288")
     return {"bound": "hbm", "kernel": f"k_dense_mv (y = C x, d={d}, f64, bs=1)", "achieved": round(ach, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": mv_bytes, "us_per_apply": round(t_mv * 1e6, 1),
             "rank2_update": {"kernel": "k_dense_rank2", "achieved": round(r2_bytes / t_r2 / 1e9, 1), "unit": "GB/s",
                              "frac": round(r2_bytes / t_r2 / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": r2_bytes,
