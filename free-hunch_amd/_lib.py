@@ -31,6 +31,12 @@ class FhBatch(C.Structure):
                 ("B", c_dp * FH_MAX_BATCH), ("M", c_dp * FH_MAX_BATCH), ("mask", c_dp * FH_MAX_BATCH)]
 
 
+class FhCovState(C.Structure):
+    _fields_ = [("d", C.c_int64), ("m_c", C.c_int32), ("m_h", C.c_int32), ("ldm", C.c_int32), ("ldg", C.c_int32),
+                ("project", C.c_int32), ("use_dct", C.c_int32), ("D", c_dp * 4), ("r", c_dp * 4), ("M", c_dp * 4),
+                ("Bc", c_dp), ("Bh", c_dp), ("G", c_dp), ("scal", c_dp), ("t0", c_dp), ("t1", c_dp), ("t2", c_dp)]
+
+
 class FhCgInfo(C.Structure):
     _fields_ = [("niter", C.c_int32), ("optimal", C.c_int32), ("residual_norm", C.c_double),
                 ("b_norm", C.c_double)]
@@ -51,6 +57,9 @@ _SIGS = {
                          c_dp, c_dp, c_dp, C.c_int, C.c_int64, C.c_void_p], C.c_int),
     "fh_space_commit_dev": ([C.c_void_p, c_dp, c_dp, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                              c_dp, C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p], C.c_int),
+    "fh_cov_time_update": ([C.c_void_p, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_int,
+                            c_dp, c_dp, c_dp, c_dp, C.c_void_p], C.c_int),
+    "fh_cov_space_update": ([C.c_void_p, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, c_dp, c_dp, C.c_void_p], C.c_int),
     "fh_woodbury_inner": ([C.c_void_p, c_dp, C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_axpby": ([C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
     "fh_read_scalars": ([C.c_void_p, c_dp, C.POINTER(C.c_double), C.c_int, C.c_void_p], C.c_int),

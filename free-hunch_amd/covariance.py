@@ -18,6 +18,7 @@ fh_space_*); the m x m algebra (m <= 2 * number of space updates) stays on the h
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import os
 
@@ -150,6 +151,17 @@ class CovarianceHessianBFGS:
             _lib.check(rc, "fh_woodbury_inner")
         dst.set_M(_woodbury_inner(src.M, self._G[:m, :m].cpu().numpy()))  # m > 64: host LU
 
+    def _state(self):
+        st = _lib.FhCovState()
+        st.d, st.m_c, st.m_h = self.data_dim, self.famC.m, self.famH.m
+        st.ldm, st.ldg = self.C.M_dev.shape[1], self._G.shape[1]
+        st.project, st.use_dct = int(bool(self.project_to_diagonal)), int(self.use_dct)
+        for i, rep in enumerate((self.C, self.Ci, self.H, self.Hi)):
+            st.D[i], st.r[i], st.M[i] = rep.D.data_ptr(), rep.r.data_ptr(), rep.M_dev.data_ptr()
+        st.Bc, st.Bh, st.G, st.scal = self.famC.B.data_ptr(), self.famH.B.data_ptr(), self._G.data_ptr(), self._scal.data_ptr()
+        st.t0, st.t1, st.t2 = self._t0.data_ptr(), self._t1.data_ptr(), self._t2.data_ptr()
+        return st
+
     def _apply(self, rep, fam, z, out):
         return self.ctx.rep_apply(rep.D, rep.r, fam.B, rep.M_dev, z, out, fam.m)
 
@@ -194,14 +206,34 @@ class CovarianceHessianBFGS:
         assert shape[0] == 1, "Batch size must be 1"
         sigma_t, sigma_tnext = float(sigma_t), float(sigma_tnext)
         # the reference multiplies the increment by a float32 `torch.ones` (:166, :172): float32-rounded scalars
-        self._invert(self.Ci, self.C, self.famC, shift=float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2))))
+        shift_c = float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2)))
+        shift_h = -float(np.float32(sigma_tnext ** 2 - sigma_t ** 2))
+        if max(self.famC.m, self.famH.m) <= 64 and os.environ.get("FH_COV_STEPWISE") != "1":
+            # one C call enqueues the whole update (same kernels, same order as the step-by-step path below)
+            ctx = self.ctx
+            x = self._vec(x_t)
+            if only_covariance:
+                _lib.check(ctx.lib.fh_cov_time_update(ctx.h, C.byref(self._state()), None, None, shift_c, shift_h, 0.0, 1,
+                                                      None, None, None, None, _lib.stream()), "fh_cov_time_update")
+                self.C.m = self.famC.m
+                x = x_t.detach().to(device=self.device, dtype=F64)
+                return x.clone(), x.clone()
+            sc = self._vec(score_t)
+            wx, ws, mean, score = (torch.empty_like(x) for _ in range(4))
+            _lib.check(ctx.lib.fh_cov_time_update(ctx.h, C.byref(self._state()), _lib.ptr(x), _lib.ptr(sc), shift_c, shift_h,
+                                                  sigma_tnext ** 2, 0, _lib.ptr(wx), _lib.ptr(ws), _lib.ptr(mean),
+                                                  _lib.ptr(score), _lib.stream()), "fh_cov_time_update")
+            self.C.m = self.famC.m
+            self.H.m = self.famH.m
+            return mean.reshape(shape), score.reshape(shape)
+        self._invert(self.Ci, self.C, self.famC, shift=shift_c)
         if only_covariance:
             x = x_t.detach().to(device=self.device, dtype=F64)
             return x.clone(), x.clone()
         x = self._fwd(self._vec(x_t))
         s = self._fwd(self._vec(score_t))
         t = self._apply(self.Hi, self.famH, s, self._t0)  # old H^-1 score, before the diagonal moves
-        self._invert(self.Hi, self.H, self.famH, shift=-float(np.float32(sigma_tnext ** 2 - sigma_t ** 2)))
+        self._invert(self.Hi, self.H, self.famH, shift=shift_h)
         new_score = self._apply(self.H, self.famH, t, torch.empty_like(t))
         new_mean = self.ctx.axpby(1.0, x, sigma_tnext ** 2, new_score, torch.empty_like(x))
         return self._bwd(new_mean).reshape(shape), self._bwd(new_score).reshape(shape)
@@ -213,6 +245,19 @@ class CovarianceHessianBFGS:
         sigma_t = float(sigma_t)
         s2 = sigma_t ** 2
         d = self.data_dim
+        if max(self.famC.m, self.famH.m) + 2 <= 64 and os.environ.get("FH_COV_STEPWISE") != "1":
+            project = bool(self.project_to_diagonal)
+            mc, mh = self.famC.m, self.famH.m
+            self._ensure_capacity(max(mc if project else mc + 2, mh + 2))
+            _lib.check(lib.fh_cov_space_update(ctx.h, C.byref(self._state()), _lib.ptr(self._vec(denoiser_mean_at_x)),
+                                               _lib.ptr(self._vec(denoiser_mean_at_xnext)), s2, _lib.ptr(self._vec(x)),
+                                               _lib.ptr(self._vec(xnext)), _lib.stream()), "fh_cov_space_update")
+            if not project:
+                self.famC.m = self.C.m = self.Ci.m = mc + 2
+            self.famH.m = self.H.m = self.Hi.m = mh + 2
+            if self.max_vector_count is not None:
+                self.drop_vectors(self.max_vector_count, sigma_t)
+            return
         dx = self._fwd(ctx.axpby(1.0, self._vec(xnext), -1.0, self._vec(x), self._t0))
         dm = self._fwd(ctx.axpby(1.0, self._vec(denoiser_mean_at_xnext), -1.0, self._vec(denoiser_mean_at_x),
                                  self._t1))

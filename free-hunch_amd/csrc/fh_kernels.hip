@@ -1385,6 +1385,64 @@ int fh_axpby(double alpha, const double* a, double beta, const double* b, double
   return 0;
 }
 
+// ---- whole covariance updates (see fh_hip.h): the step-by-step entry points, enqueued from C in covariance.py's order
+static int cov_invert(fh_context* ctx, const fh_cov_state* st, int src, int dst, const double* B, int m, double shift,
+                      void* stream) {
+  int rc = fh_rep_invert(ctx, st->D[src], st->r[src], B, shift, st->D[dst], st->r[dst], st->G, st->ldg, st->d, m, stream);
+  if (rc) return rc;
+  return fh_woodbury_inner(ctx, st->M[src], st->ldm, st->G, st->ldg, st->M[dst], st->ldm, m, stream);
+}
+
+static int cov_fwd(fh_context* ctx, const fh_cov_state* st, const double* in, double* out, int inverse, void* stream) {
+  if (st->use_dct) return fh_dct2d(ctx, in, out, 3, inverse, stream);
+  if (in != out) return fh_axpby(1.0, in, 0.0, nullptr, out, st->d, stream);
+  return 0;
+}
+
+int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x, const double* score, double shift_c,
+                       double shift_h, double sigma_next2, int only_covariance, double* wx, double* ws,
+                       double* mean_out, double* score_out, void* stream) {
+  if (!ctx || !st || st->m_c > kWbMax || st->m_h > kWbMax) return !ctx || !st ? FH_EINVAL : FH_ESIZE;
+  int rc = cov_invert(ctx, st, 1, 0, st->Bc, st->m_c, shift_c, stream);  // C <- (C^-1 + shift)^-1
+  if (rc || only_covariance) return rc;
+  if (!x || !score || !wx || !ws || !mean_out || !score_out) return FH_EINVAL;
+  if ((rc = cov_fwd(ctx, st, x, wx, 0, stream))) return rc;
+  if ((rc = cov_fwd(ctx, st, score, ws, 0, stream))) return rc;
+  // t0 = H^-1 score with the OLD Hessian, then H <- (H^-1 + shift)^-1, new score = H t0
+  if ((rc = fh_rep_apply(ctx, st->D[3], st->r[3], st->Bh, st->M[3], st->ldm, ws, st->t0, st->d, st->m_h, stream))) return rc;
+  if ((rc = cov_invert(ctx, st, 3, 2, st->Bh, st->m_h, shift_h, stream))) return rc;
+  if ((rc = fh_rep_apply(ctx, st->D[2], st->r[2], st->Bh, st->M[2], st->ldm, st->t0, ws, st->d, st->m_h, stream))) return rc;
+  if ((rc = fh_axpby(1.0, wx, sigma_next2, ws, wx, st->d, stream))) return rc;  // mean' = x + s'^2 score'
+  if ((rc = cov_fwd(ctx, st, wx, mean_out, 1, stream))) return rc;
+  return cov_fwd(ctx, st, ws, score_out, 1, stream);
+}
+
+int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* mean_x, const double* mean_xn, double s2,
+                        const double* x, const double* xn, void* stream) {
+  if (!ctx || !st || !mean_x || !mean_xn || !x || !xn) return FH_EINVAL;
+  if (st->m_c + 2 > kWbMax || st->m_h + 2 > kWbMax) return FH_ESIZE;
+  const int mc = st->m_c, mh = st->m_h;
+  if (st->ldm < (st->project ? mc : mc + 2) || st->ldm < mh + 2) return FH_EINVAL;
+  int rc;
+  double *dx = st->t0, *de = st->t1, *cdx = st->t2;
+  if ((rc = fh_axpby(1.0, xn, -1.0, x, dx, st->d, stream))) return rc;
+  if ((rc = cov_fwd(ctx, st, dx, dx, 0, stream))) return rc;
+  if ((rc = fh_axpby(1.0, mean_xn, -1.0, mean_x, de, st->d, stream))) return rc;
+  if ((rc = cov_fwd(ctx, st, de, de, 0, stream))) return rc;
+  if ((rc = fh_space_prep(ctx, de, s2, dx, de, st->scal, st->d, stream))) return rc;  // de <- s2 dm; scal[0] = dx.de
+  if ((rc = fh_rep_apply(ctx, st->D[0], st->r[0], st->Bc, st->M[0], st->ldm, dx, cdx, st->d, mc, stream))) return rc;
+  if ((rc = fh_dot(ctx, cdx, dx, st->scal, 1, st->d, stream))) return rc;              // scal[1] = dx.(C dx)
+  double* bc0 = st->project ? nullptr : st->Bc + (int64_t)mc * st->d;
+  double* bc1 = st->project ? nullptr : st->Bc + (int64_t)(mc + 1) * st->d;
+  if ((rc = fh_space_commit_dev(ctx, de, cdx, st->scal, s2, st->D[0], st->r[0], bc0, bc1, st->D[2], st->r[2],
+                                st->Bh + (int64_t)mh * st->d, st->Bh + (int64_t)(mh + 1) * st->d, st->M[0], st->ldm, mc,
+                                st->M[2], st->ldm, mh, st->project, st->d, stream)))
+    return rc;
+  const int mc2 = st->project ? mc : mc + 2, mh2 = mh + 2;
+  if ((rc = cov_invert(ctx, st, 0, 1, st->Bc, mc2, 0.0, stream))) return rc;  // C^-1
+  return cov_invert(ctx, st, 2, 3, st->Bh, mh2, 0.0, stream);                 // H^-1
+}
+
 int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k, void* stream) {
   if (!ctx || !scal || !out_host || k < 1 || k > 64) return FH_EINVAL;
   FH_CHECK(hipMemcpyAsync(ctx->h_scal, scal, sizeof(double) * k, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -78,6 +78,40 @@ int fh_space_commit_dev(fh_context* ctx, const double* de, const double* cdx, co
                         double* Bh_col0, double* Bh_col1, double* Mc, int ldc, int mc, double* Mh, int ldh, int mh,
                         int project, int64_t d, void* stream);
 
+/* ---- whole covariance updates in one call ---------------------------------------------------------------------------
+ * update_time_step (online_update_bfgs.py:153-192) and update_space_step (:250-312) as single entry points: the ~35
+ * kernel launches of an update are enqueued from C (same kernels, same order as the step-by-step entry points above),
+ * so that the host thread of an image spends microseconds, not milliseconds, per guidance call.
+ * Representations are indexed C = 0, C^-1 = 1, H = 2, H^-1 = 3; all pointers are device memory owned by the caller;
+ * the caller grows the bases / inner matrices BEFORE a space update (m_c + 2, m_h + 2 <= capacity) and bumps its own
+ * column counts afterwards (m_c += 2 unless project, m_h += 2). */
+typedef struct fh_cov_state {
+  int64_t d;
+  int32_t m_c, m_h;      /* columns of the covariance / Hessian base */
+  int32_t ldm, ldg;      /* leading dimensions of the inner matrices and of the Gram scratch */
+  int32_t project;       /* project_to_diagonal */
+  int32_t use_dct;       /* 1: vectors are transformed with fh_dct2d (3 planes), 0: identity basis */
+  double* D[4];
+  double* r[4];
+  double* M[4];
+  double* Bc;            /* [cap][d] */
+  double* Bh;
+  double* G;             /* [ldg][ldg] */
+  double* scal;          /* >= 8 device scalars */
+  double* t0;            /* three d-vectors of scratch */
+  double* t1;
+  double* t2;
+} fh_cov_state;
+
+/* x, score: image-space d-vectors; wx, ws: d-vectors of scratch; mean_out, score_out: results (image space).
+ * shift_c = float32(s'^-2 - s^-2), shift_h = -float32(s'^2 - s^2) (the reference's float32-rounded increments). */
+int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x, const double* score, double shift_c,
+                       double shift_h, double sigma_next2, int only_covariance, double* wx, double* ws,
+                       double* mean_out, double* score_out, void* stream);
+/* mean_x, mean_xn, x, xn: image-space d-vectors; s2 = sigma^2. */
+int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* mean_x, const double* mean_xn, double s2,
+                        const double* x, const double* xn, void* stream);
+
 /* The m x m algebra of the Woodbury step above on the device (m <= 64; FH_ESIZE beyond, the caller then uses its host
  * path):  Mdst[:m,:m] = sym( -Msrc (I + G Msrc)^-1 ), Gauss-Jordan with partial pivoting in one workgroup.
  * Replaces the D2H copy + numpy.linalg.inv + H2D copy of an update, so that update_time_step / update_space_step

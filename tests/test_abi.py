@@ -31,6 +31,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.FhProblem) == 8 * 4 + 8 + 8 + 8 * 8 + 8 + 3 * 8
     assert _lib.FhProblem.d.offset == 32 and _lib.FhProblem.sigma_y2.offset == 40
     assert _lib.FhProblem.tap_dy.offset == 48 and _lib.FhProblem.M.offset == 104
+    # struct fh_cov_state: int64 d, 6 x int32, 3 x (4 pointers), 7 pointers
+    assert ctypes.sizeof(_lib.FhCovState) == 8 + 6 * 4 + 12 * 8 + 7 * 8 and _lib.FhCovState.D.offset == 32
     assert ctypes.sizeof(_lib.FhCgInfo) == 24
 
 
