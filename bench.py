@@ -298,6 +298,86 @@ def cpu_baseline(arch, operator_name, num_steps, data_dir, calls=4):
                       f"this slightly under-states the CPU rate"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, env=None, timeout=None):
+    """Start one child process per GPU (the launch model of the reference's torch_utils/distributed.py:19-45: env://
+    rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for all of them.  Rank 0's child
+    prints the JSON line on the inherited stdout.  Returns the first non-zero child exit code (0 if all succeeded);
+    when one rank fails the others are terminated, so a dead rank cannot leave the rest hanging in a collective."""
+    import subprocess
+    script = os.path.abspath(__file__) if script is None else script
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base.get("MASTER_PORT") or _free_port()),
+                HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e))
+    rc, t_end = 0, None if timeout is None else time.monotonic() + timeout
+    pending = list(procs)
+    while pending:
+        for p_ in list(pending):
+            code = p_.poll()
+            if code is None:
+                continue
+            pending.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code
+                for q_ in pending:  # exact PIDs we started
+                    q_.terminate()
+        if pending:
+            if t_end is not None and time.monotonic() > t_end:
+                rc = rc or 124
+                for q_ in pending:
+                    q_.kill()
+            time.sleep(0.2)
+    return rc
+
+
+def exchange(out_u8, world, coll):
+    """The path's one exchange step: ONE all_gather of the finished uint8 images of every rank (inside the timed
+    region).  `coll` is the device the collective runs on (the GPU under RCCL; the CPU in the gloo rehearsal)."""
+    if world == 1:
+        return [out_u8]
+    import torch.distributed as dist
+    src = out_u8.to(coll)
+    bufs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(bufs, src)
+    return bufs
+
+
+def run_steps(step, steps, warmup, world, coll, device_sync):
+    """The bench contract's timing: `warmup` untimed steps, then exactly `steps` steps bracketed by device sync + barrier
+    on both sides; returns the MAX over ranks of the elapsed seconds."""
+    import torch.distributed as dist
+
+    def sync():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    for i in range(warmup):
+        step(-1 - i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +393,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=4)
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher.  Nothing above has touched the GPU (importing torch
+        # does not), and the ranks are CHILD processes - a process that has initialised HIP is never re-exec'ed.
+        rc = launch_ranks(a.gpus, sys.argv[1:])
+        sys.exit(rc if rc >= 0 else 128 - rc)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -342,33 +428,13 @@ def main():
     net, cfg = build_net(a.arch, device, a.unet_backend)
     images = smooth_images(a.batch, 256, 1234 + rank)
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def step(i):
         seeds = [(i * world + rank) * a.batch + j for j in range(a.batch)]
         out = run_batch(net, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir, a.groups)
-        if world > 1:  # the path's one exchange: gather the finished uint8 images
-            src = out.to(coll)
-            bufs = [torch.empty_like(src) for _ in range(world)]
-            dist.all_gather(bufs, src)
+        exchange(out, world, coll)
         return out
 
-    for i in range(a.warmup):
-        step(-1 - i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed = run_steps(step, a.steps, a.warmup, world, coll, torch.cuda.synchronize)
 
     if rank == 0:
         total_images = a.steps * a.batch * world

@@ -147,7 +147,9 @@ def solve_customcuda_batched(operators, ys, x0_means, covariance_models, max_rto
         raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
                          "'motion_blur', or 'inpainting'.")
     dev, S = cov0.device, cov0.S
-    ctx = _lib.Context.get(S, 3 * B, 0, slot=5000 + B)  # scratch sized for the whole batch
+    # scratch sized for the whole batch; one context per lock-step GROUP (keyed by the group's first image slot), so
+    # that equal-sized groups running concurrently from different host threads never share CG vectors or graph caches
+    ctx = _lib.Context.get(S, 3 * B, 0, slot=5000 + 64 * int(getattr(op0, "ctx_slot", 0)) + B)
     prob, keep = _problem(op0, cov0, _sigma_y2(op0))
     per = _lib.FhBatch()
     per.nimg = B

@@ -69,6 +69,30 @@ class _Family:
         self.B = new
 
 
+def _csqrtm(A):
+    """The reference's `sqrtm` wrapper (online_update_bfgs.py:67-71): scipy's principal square root, complex128."""
+    if A.shape[0] == 0:
+        return np.zeros_like(A, dtype=np.complex128)
+    from scipy.linalg import sqrtm
+    return np.asarray(sqrtm(A)).astype(np.complex128)
+
+
+def _woodbury_factors(QU, QV, G):
+    """The m x k algebra of `woodbury_inverse_from_diag_plus_lowrank_minus_lowrank` (online_update_bfgs.py:87-119) in the
+    coordinates of the shared base.  The reference's factors are U = diag(r) B QU, V = diag(r) B QV (complex128, plain
+    transposes); with G = B^T diag(r^2 / D) B the inverse's factors are diag(r / D) B QUi, diag(r / D) B QVi."""
+    k = QU.shape[1]
+    eye = np.eye(k)
+    inner = np.linalg.inv(eye + QU.T @ G @ QU) if k else np.zeros((0, 0), np.complex128)
+    inner = (inner + inner.T) / 2                              # :98-99
+    QVi = QU @ _csqrtm(inner)                                  # :102-104
+    K = QVi.T @ G @ QV                                         # :115  V_inv^T V
+    inner2 = np.linalg.inv(eye - QV.T @ G @ QV + K.T @ K) if k else inner
+    S2 = _csqrtm(inner2)                                       # :116-117
+    QUi = QV @ S2 - QVi @ (K @ S2)                             # :118-119
+    return QUi, QVi
+
+
 def _woodbury_inner(M, G):
     """M_inv = -M (I + G M)^-1, symmetrised (the m x m part of online_update_bfgs.py:87-119)."""
     m = M.shape[0]
@@ -109,13 +133,19 @@ class CovarianceHessianBFGS:
         self._G = torch.zeros(m_cap, m_cap, dtype=F64, device=self.device)
         self._scal = torch.zeros(8, dtype=F64, device=self.device)
         self._t0, self._t1, self._t2 = (torch.empty(d, dtype=F64, device=self.device) for _ in range(3))
+        # `0 < max_vector_count`: the reference keeps "the newest columns" of its sqrtm-mixed factors (:240-244), so those
+        # factors must exist.  They are tracked in base coordinates (m x k complex matrices QU, QV per representation of
+        # the C family - host algebra on a few dozen numbers, the d-sized work stays in the kernels); a count that the
+        # column capacity can never reach needs no tracking and keeps the transfer-free fused path.
+        self._track = max_vector_count is not None and 0 < max_vector_count < _lib_max_cols() // 2
+        self._Q = {"C": (np.zeros((0, 0), np.complex128),) * 2, "Ci": (np.zeros((0, 0), np.complex128),) * 2}
         self._derive_from_cov(np.sqrt(init_noise_variance))
 
     # ------------------------------------------------------------------ helpers
     @property
     def k(self):
         """number of stored (u, v) pairs of the covariance (reference: vectors_denoiser_cov_u.shape[-1])"""
-        return self.famC.m // 2
+        return self._Q["C"][0].shape[1] if self._track else self.famC.m // 2
 
     def _ensure_capacity(self, need):
         if need <= self.m_cap:
@@ -150,6 +180,34 @@ class CovarianceHessianBFGS:
         if rc != _lib.FH_ESIZE:
             _lib.check(rc, "fh_woodbury_inner")
         dst.set_M(_woodbury_inner(src.M, self._G[:m, :m].cpu().numpy()))  # m > 64: host LU
+
+    def _invert_tracked(self, src, dst, src_key, dst_key, shift=0.0):
+        """`_invert` for the C family with the reference's factor bookkeeping: the Gram matrix comes back to the host
+        (m x m), the factor coordinates follow :87-119 and dst.M = QUi QUi^T - QVi QVi^T."""
+        fam = self.famC
+        m = fam.m
+        self.ctx.rep_invert(src.D, src.r, fam.B, shift, dst.D, dst.r, self._G, m)
+        if m == 0:
+            dst.m = 0
+            self._Q[dst_key] = self._Q[src_key]
+            return
+        G = self._G[:m, :m].cpu().numpy()
+        QUi, QVi = _woodbury_factors(*self._Q[src_key], G)
+        self._Q[dst_key] = (QUi, QVi)
+        dst.set_M(self._real_inner(QUi @ QUi.T - QVi @ QVi.T))
+
+    @staticmethod
+    def _real_inner(M):
+        """U U^T - V V^T is real whenever every stored pair is complete; after a truncation that splits a
+        negative-curvature pair the reference carries a complex matrix internally and takes `.real` of each product
+        (:202).  The kernels are real: keep the real part and say so."""
+        im = float(np.abs(M.imag).max()) if M.size else 0.0
+        if im > 1e-9 * max(1.0, float(np.abs(M.real).max()) if M.size else 0.0):
+            import warnings
+            warnings.warn("max_vector_count truncated a negative-curvature pair: the reference's inner matrix is complex "
+                          f"here (|imag| = {im:.2e}); its real part is kept")
+        M = np.ascontiguousarray(M.real)
+        return 0.5 * (M + M.T)
 
     def _state(self):
         st = _lib.FhCovState()
@@ -208,7 +266,7 @@ class CovarianceHessianBFGS:
         # the reference multiplies the increment by a float32 `torch.ones` (:166, :172): float32-rounded scalars
         shift_c = float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2)))
         shift_h = -float(np.float32(sigma_tnext ** 2 - sigma_t ** 2))
-        if max(self.famC.m, self.famH.m) <= 64 and os.environ.get("FH_COV_STEPWISE") != "1":
+        if max(self.famC.m, self.famH.m) <= 64 and os.environ.get("FH_COV_STEPWISE") != "1" and not self._track:
             # one C call enqueues the whole update (same kernels, same order as the step-by-step path below)
             ctx = self.ctx
             x = self._vec(x_t)
@@ -226,7 +284,10 @@ class CovarianceHessianBFGS:
             self.C.m = self.famC.m
             self.H.m = self.famH.m
             return mean.reshape(shape), score.reshape(shape)
-        self._invert(self.Ci, self.C, self.famC, shift=shift_c)
+        if self._track:
+            self._invert_tracked(self.Ci, self.C, "Ci", "C", shift=shift_c)
+        else:
+            self._invert(self.Ci, self.C, self.famC, shift=shift_c)
         if only_covariance:
             x = x_t.detach().to(device=self.device, dtype=F64)
             return x.clone(), x.clone()
@@ -245,13 +306,15 @@ class CovarianceHessianBFGS:
         sigma_t = float(sigma_t)
         s2 = sigma_t ** 2
         d = self.data_dim
-        if max(self.famC.m, self.famH.m) + 2 <= 64 and os.environ.get("FH_COV_STEPWISE") != "1":
+        if max(self.famC.m, self.famH.m) + 2 <= 64 and os.environ.get("FH_COV_STEPWISE") != "1" and not self._track:
             project = bool(self.project_to_diagonal)
             mc, mh = self.famC.m, self.famH.m
             self._ensure_capacity(max(mc if project else mc + 2, mh + 2))
-            _lib.check(lib.fh_cov_space_update(ctx.h, C.byref(self._state()), _lib.ptr(self._vec(denoiser_mean_at_x)),
-                                               _lib.ptr(self._vec(denoiser_mean_at_xnext)), s2, _lib.ptr(self._vec(x)),
-                                               _lib.ptr(self._vec(xnext)), _lib.stream()), "fh_cov_space_update")
+            # locals keep the (possibly converted) inputs alive until the launch: a temporary freed between two
+            # `_vec` calls would hand the same cached block to the next one
+            mx, mxn, vx, vxn = (self._vec(t) for t in (denoiser_mean_at_x, denoiser_mean_at_xnext, x, xnext))
+            _lib.check(lib.fh_cov_space_update(ctx.h, C.byref(self._state()), _lib.ptr(mx), _lib.ptr(mxn), s2,
+                                               _lib.ptr(vx), _lib.ptr(vxn), _lib.stream()), "fh_cov_space_update")
             if not project:
                 self.famC.m = self.C.m = self.Ci.m = mc + 2
             self.famH.m = self.H.m = self.Hi.m = mh + 2
@@ -284,7 +347,21 @@ class CovarianceHessianBFGS:
         if not project:
             self.famC.m = self.C.m = mc + 2
         self.famH.m = self.H.m = mh + 2
-        self._invert(self.C, self.Ci, self.famC)
+        if self._track:
+            if not project:
+                # the new pair in base coordinates: u = sqrt(gamma) * column mc, v = column mc+1 / sqrt(q) (:271-272);
+                # a negative gamma gives an imaginary u exactly as torch.sqrt does on the reference's complex scalars
+                dxde, q = ctx.read_scalars(self._scal, 2)
+                QU, QV = self._Q["C"]
+                k = QU.shape[1]
+                QU2, QV2 = np.zeros((mc + 2, k + 1), np.complex128), np.zeros((mc + 2, k + 1), np.complex128)
+                QU2[:mc, :k], QV2[:mc, :k] = QU, QV
+                QU2[mc, k] = np.sqrt(complex(1.0 / dxde))
+                QV2[mc + 1, k] = 1.0 / np.sqrt(complex(q))
+                self._Q["C"] = (QU2, QV2)
+            self._invert_tracked(self.C, self.Ci, "C", "Ci")
+        else:
+            self._invert(self.C, self.Ci, self.famC)
         self._invert(self.H, self.Hi, self.famH)
         if self.max_vector_count is not None:
             self.drop_vectors(self.max_vector_count, sigma_t)
@@ -293,11 +370,34 @@ class CovarianceHessianBFGS:
     def drop_vectors(self, max_vector_count, sigma):
         if max_vector_count == 0:
             self.famC.m = 0
+            self._Q["C"] = (np.zeros((0, 0), np.complex128),) * 2
             self._derive_from_cov(sigma)
         elif self.k > max_vector_count:
-            raise NotImplementedError(
-                "0 < max_vector_count < k drops columns of the reference's sqrtm-mixed complex factors "
-                "(online_update_bfgs.py:240-244); that factorisation is not kept on the device")
+            # keep the newest columns of U and V (:240-243).  The base keeps all its columns (they are raw pairs, never
+            # rewritten); the truncation lives in the inner matrix M = QU QU^T - QV QV^T of rank <= 2 max_vector_count.
+            assert self._track, "internal: truncation without factor tracking"
+            n = max_vector_count
+            QU, QV = self._Q["C"]
+            QU, QV = QU[:, -n:], QV[:, -n:]
+            self._Q["C"] = (QU, QV)
+            self.C.set_M(self._real_inner(QU @ QU.T - QV @ QV.T))
+            self._rederive_after_truncation(sigma)
+
+    def _rederive_after_truncation(self, sigma):
+        """set_others_corresponding_to_current_denoiser_cov (:327-330) for a non-empty factor: C^-1 by Woodbury, the
+        Hessian re-built FROM the covariance (H = (C / s^2 - I) / s^2, i.e. the same factors / s^2), then H^-1."""
+        s2 = float(sigma) ** 2
+        m = self.famC.m
+        self._invert_tracked(self.C, self.Ci, "C", "Ci")
+        self._ensure_capacity(m)
+        self.famH.B[:m].copy_(self.famC.B[:m])  # the Hessian family now spans the covariance's columns
+        self.famH.m = m
+        self.H.r.copy_(self.C.r)
+        torch.div(self.C.D, s2, out=self.H.D)
+        self.H.D.sub_(1.0).div_(s2)
+        self.H.M_dev[:m, :m].copy_(self.C.M_dev[:m, :m] / (s2 * s2))
+        self.H.m = m
+        self._invert(self.H, self.Hi, self.famH)
 
     # ------------------------------------------------------------------ :320-325 (small d, tests only)
     def get_dense_matrices(self):

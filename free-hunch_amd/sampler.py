@@ -38,6 +38,23 @@ class StandardRGBEncoder:  # training/encoders.py:61-73
         return (x.to(torch.float32) * 127.5 + 128).clip(0, 255).to(torch.uint8)
 
 
+def _make_mechanism(o, forward_operator, sigma0, data_dim):
+    """The plugin instance of one image, built exactly as generate_conditional.py:120-130 does."""
+    return choose_conditioning_mechanism(o["conditioning_mechanism"])(
+        o["cond_scaling"], forward_operator, o["clip_x0_mean"], init_denoiser_variance=1,
+        init_noise_variance=torch.tensor(sigma0, dtype=torch.float64) ** 2, data_dim=data_dim,
+        pigdm_posthoc_scaling=o.get("pigdm_posthoc_scaling", False), max_vector_count=o["max_vector_count"],
+        data_dir=o["dataset_path"], image_base_covariance=o["image_base_covariance"],
+        pca_component_count=o.get("pca_component_count", 10),
+        denoiser_mean_error_threshold=o["denoiser_mean_error_threshold"],
+        use_analytical_score_time_update=o["use_analytical_score_time_update"],
+        project_to_diagonal=o["project_to_diagonal"], space_step_update_threshold=o["space_step_update_threshold"],
+        space_step_update_lower_threshold=o["space_step_update_lower_threshold"], max_rtol=o["max_rtol"],
+        do_space_updates=o["do_space_updates"], use_analytic_var_at_end=o.get("use_analytic_var_at_end", False),
+        solver_type=o.get("solver_type", "customcuda"), use_rtol_func=o.get("use_rtol_func", False),
+        diffpir_lambda=o.get("diffpir_lambda", 10.0))
+
+
 def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=None, labels=None,
                         randn_like=torch.randn_like, num_steps=18, sigma_min=None, sigma_max=None, rho=7,
                         solver="heun", discretization="edm", schedule="linear", scaling="none", S_churn=0, S_min=0,
@@ -62,20 +79,7 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
 
     x_next = noise.to(torch.float64) * t_list[0]
     x_all = [x_next.detach()]
-    o = other_args
-    mech = choose_conditioning_mechanism(o["conditioning_mechanism"])(
-        o["cond_scaling"], forward_operator, o["clip_x0_mean"], init_denoiser_variance=1,
-        init_noise_variance=torch.tensor(t_list[0], dtype=torch.float64) ** 2, data_dim=x_next.shape[1:].numel(),
-        pigdm_posthoc_scaling=o.get("pigdm_posthoc_scaling", False), max_vector_count=o["max_vector_count"],
-        data_dir=o["dataset_path"], image_base_covariance=o["image_base_covariance"],
-        pca_component_count=o.get("pca_component_count", 10),
-        denoiser_mean_error_threshold=o["denoiser_mean_error_threshold"],
-        use_analytical_score_time_update=o["use_analytical_score_time_update"],
-        project_to_diagonal=o["project_to_diagonal"], space_step_update_threshold=o["space_step_update_threshold"],
-        space_step_update_lower_threshold=o["space_step_update_lower_threshold"], max_rtol=o["max_rtol"],
-        do_space_updates=o["do_space_updates"], use_analytic_var_at_end=o.get("use_analytic_var_at_end", False),
-        solver_type=o.get("solver_type", "customcuda"), use_rtol_func=o.get("use_rtol_func", False),
-        diffpir_lambda=o.get("diffpir_lambda", 10.0))
+    mech = _make_mechanism(other_args, forward_operator, t_list[0], x_next.shape[1:].numel())
     y = cond_images.to(noise.device)
     f64 = lambda v: torch.tensor(v, dtype=torch.float64, device=noise.device)
     for i, (t_cur, t_next) in enumerate(zip(t_list[:-1], t_list[1:])):
@@ -122,19 +126,14 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
     t_steps = net.round_sigma(get_sigma_steps("edm", num_steps, sigma_min, sigma_max, rho, dev))
     t_list = [float(t) for t in t_steps] + [0.0]
     o = other_args
+    if o.get("discretization", "edm") != "edm" or o.get("schedule", "linear") != "linear" or o.get("scaling", "none") != "none":
+        raise NotImplementedError("only the 'edm' discretisation with sigma(t)=t, s(t)=1 is on the Free Hunch path")
+    if o.get("S_churn", 0) != 0:
+        raise NotImplementedError("the lock-step sampler is deterministic (S_churn = 0); use conditional_sampler")
     mechs = []
     for b in range(B):
         assert getattr(operators[b], "ctx_slot", 0) == slot_base + b, "every concurrent image needs its own ctx_slot"
-        mechs.append(choose_conditioning_mechanism(o["conditioning_mechanism"])(
-            o["cond_scaling"], operators[b], o["clip_x0_mean"], init_denoiser_variance=1,
-            init_noise_variance=torch.tensor(t_list[0], dtype=torch.float64) ** 2, data_dim=noise.shape[1:].numel(),
-            max_vector_count=o["max_vector_count"], data_dir=o["dataset_path"],
-            image_base_covariance=o["image_base_covariance"],
-            denoiser_mean_error_threshold=o["denoiser_mean_error_threshold"],
-            use_analytical_score_time_update=o["use_analytical_score_time_update"],
-            project_to_diagonal=o["project_to_diagonal"], space_step_update_threshold=o["space_step_update_threshold"],
-            space_step_update_lower_threshold=o["space_step_update_lower_threshold"], max_rtol=o["max_rtol"],
-            do_space_updates=o["do_space_updates"], solver_type=o.get("solver_type", "customcuda")))
+        mechs.append(_make_mechanism(o, operators[b], t_list[0], noise.shape[1:].numel()))
     ys = [m.to(dev) for m in measurements]
     streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)

@@ -57,70 +57,82 @@ def main(argv=None):
     total = len(files)
     mine = shard_indices(total, rank, world)
     enc = StandardRGBEncoder()
+    data_dir = o.dataset_path if os.path.exists(os.path.join(o.dataset_path, "dct_variance.pt")) else \
+        os.path.join(ROOT, "free-hunch_amd", "data")
+    # every option the reference forwards to its sampler / plugin (generate_conditional.py:121-130, 495)
     kw = dict(conditioning_mechanism=o.conditioning_mechanism, cond_scaling=o.cond_scaling, clip_x0_mean=o.clip_x0_mean,
-              max_vector_count=o.max_vector_count, dataset_path=os.path.join(ROOT, "free-hunch_amd", "data")
-              if not os.path.exists(os.path.join(o.dataset_path, "dct_variance.pt")) else o.dataset_path,
-              image_base_covariance=o.image_base_covariance,
+              pigdm_posthoc_scaling=o.pigdm_posthoc_scaling, max_vector_count=o.max_vector_count, dataset_path=data_dir,
+              image_base_covariance=o.image_base_covariance, pca_component_count=o.pca_component_count,
               denoiser_mean_error_threshold=o.denoiser_mean_error_threshold,
               use_analytical_score_time_update=o.use_analytical_score_time_update,
               project_to_diagonal=o.project_to_diagonal, space_step_update_threshold=o.space_step_update_threshold,
               space_step_update_lower_threshold=o.space_step_update_lower_threshold, max_rtol=o.max_rtol,
-              do_space_updates=o.do_space_updates, solver_type=o.solver_type)
+              do_space_updates=o.do_space_updates, use_analytic_var_at_end=o.use_analytic_var_at_end,
+              solver_type=o.solver_type, use_rtol_func=o.use_rtol_func, diffpir_lambda=o.diffpir_lambda)
+    loop = dict(num_steps=o.num_steps, sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver,
+                discretization=o.discretization, schedule=o.schedule, scaling=o.scaling)
+    churn = dict(S_churn=o.S_churn, S_min=o.S_min, S_max=o.S_max, S_noise=o.S_noise)
+    # the lock-step sampler covers the deterministic loop; stochastic churn runs image by image like the reference
+    lockstep = o.conditioning_mechanism == "online_covariance" and o.S_churn == 0
     outs, conds, fwds = [], [], []
-    seed = o.seeds[0]
-    for s in range(0, len(mine), o.max_batch_size):
-        idxs = mine[s: s + o.max_batch_size]
+    # one unit = (image, seed): the reference repeats every image once per seed (generate_conditional.py:378-390)
+    units = [(i, sd) for i in mine for sd in o.seeds]
+    for s in range(0, len(units), max(1, o.max_batch_size)):
+        chunk = units[s: s + max(1, o.max_batch_size)]
         ops, ys, noise, imgs = [], [], [], []
-        for b, i in enumerate(idxs):
-            key = (seed * 1000003 + i) % (1 << 31)  # RNG keyed by (seed, image index): independent of the world size
+        for b, (i, sd) in enumerate(chunk):
+            key = (sd * 1000003 + i) % (1 << 31)  # RNG keyed by (seed, image index): independent of the world size
             np.random.seed(key)
             torch.manual_seed(key)
             op = get_operator(name=o.operator_name, device=device, sigma_s=o.noise_sigma, kernel_size=o.kernel_size,
                               intensity=o.intensity, scale_factor=o.scale_factor, in_shape=(1, 3, S, S),
                               mask_opt={"mask_type": o.inpainting_type, "mask_len_range": (64, 156),
-                                        "mask_prob_range": (o.inpainting_prob_lower, o.inpainting_prob_upper),
-                                        "image_size": S})
+                                        "mask_prob_range": (o.inpainting_prob_lower, o.inpainting_prob_upper)
+                                        if o.inpainting_type == "random" else (0.1, 0.3), "image_size": S})
             op.ctx_slot = b
             img = load_image_u8(files[i], S)
             imgs.append(img)
             ops.append(op)
             ys.append(op.forward(enc.encode(img[None].to(device)), noiseless=False))
             noise.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(key), dtype=torch.float32))
-        if o.conditioning_mechanism == "online_covariance":
-            x = conditional_sampler_batched(net, torch.cat(noise).to(device), ys, ops, num_steps=o.num_steps,
-                                            sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver, **kw)
-        else:  # the scalar-variance comparison methods run image by image (batch 1, as in the reference)
-            x = torch.cat([conditional_sampler(net, noise[b].to(device), None, None, num_steps=o.num_steps,
-                                               sigma_min=o.sigma_min, sigma_max=o.sigma_max, rho=o.rho, solver=o.solver,
-                                               measurement=ys[b], operator=ops[b], **kw)[0].detach()
-                           for b in range(len(ops))])
+        if lockstep:
+            x = conditional_sampler_batched(net, torch.cat(noise).to(device), ys, ops, **loop, **kw)
+        else:  # comparison methods and churned runs go image by image (batch 1, as in the reference)
+            gens = [torch.Generator(device).manual_seed((sd * 1000003 + i) % (1 << 31)) for i, sd in chunk]
+            x = torch.cat([conditional_sampler(
+                net, noise[b].to(device), None, None, **loop, **churn, measurement=ys[b], operator=ops[b],
+                randn_like=lambda t, g=gens[b]: torch.randn(t.shape, generator=g, dtype=t.dtype, device=t.device),
+                **kw)[0].detach() for b in range(len(ops))])
         outs.append(enc.decode(x))
         conds.append(torch.stack(imgs).to(device))
         fwds += [enc.decode(y) for y in ys]
-        print(f"[rank {rank}] images {idxs} done", flush=True)
+        print(f"[rank {rank}] (image, seed) {chunk} done", flush=True)
     local_out = torch.cat(outs) if outs else torch.zeros((0, 3, S, S), dtype=torch.uint8, device=device)
     local_cond = torch.cat(conds) if conds else torch.zeros((0, 3, S, S), dtype=torch.uint8, device=device)
-    all_out = gather_images(local_out, mine, total, device)   # the single exchange of the run
-    all_cond = gather_images(local_cond, mine, total, device)
+    ns = len(o.seeds)
+    unit_ids = [i * ns + o.seeds.index(sd) for i, sd in units]  # global position of (image, seed)
+    all_out = gather_images(local_out, unit_ids, total * ns, device)   # the single exchange of the run
+    all_cond = gather_images(local_cond, unit_ids, total * ns, device)
+    name = lambda u: f"{u // ns:06d}_{o.seeds[u % ns]:06d}.png"
+    import PIL.Image
+    for sub in ("images", "cond_images", "forward_images"):
+        os.makedirs(os.path.join(o.outdir, sub), exist_ok=True)
     if rank == 0:
-        import PIL.Image
-        for sub in ("images", "cond_images", "forward_images"):
-            os.makedirs(os.path.join(o.outdir, sub), exist_ok=True)
-        for i in range(total):
-            name = f"{i:06d}_{seed:06d}.png"
-            PIL.Image.fromarray(all_out[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(os.path.join(o.outdir, "images", name))
-            PIL.Image.fromarray(all_cond[i].permute(1, 2, 0).cpu().numpy(), "RGB").save(
-                os.path.join(o.outdir, "cond_images", name))
+        for u in range(total * ns):
+            PIL.Image.fromarray(all_out[u].permute(1, 2, 0).cpu().numpy(), "RGB").save(
+                os.path.join(o.outdir, "images", name(u)))
+            if u % ns == 0:
+                PIL.Image.fromarray(all_cond[u].permute(1, 2, 0).cpu().numpy(), "RGB").save(
+                    os.path.join(o.outdir, "cond_images", name(u)))
         psnr, ssim = psnr_u8(all_out, all_cond), ssim_u8(all_out, all_cond)
         with open(os.path.join(o.outdir, "results.txt"), "w") as f:
-            f.write(f"PSNR: {float(psnr.mean()):.4f}\nSSIM: {float(ssim.mean()):.4f}\nimages: {total}\n")
-        print(f"PSNR {float(psnr.mean()):.3f} dB, SSIM {float(ssim.mean()):.4f} over {total} images -> {o.outdir}", flush=True)
-    for j, i in enumerate(mine):  # forward (measurement) images are written by the owning rank
+            f.write(f"PSNR: {float(psnr.mean()):.4f}\nSSIM: {float(ssim.mean()):.4f}\nimages: {total * ns}\n")
+        print(f"PSNR {float(psnr.mean()):.3f} dB, SSIM {float(ssim.mean()):.4f} over {total * ns} images -> {o.outdir}",
+              flush=True)
+    for j, u in enumerate(unit_ids):  # forward (measurement) images are written by the owning rank
         if fwds[j].shape[-1] == S:
-            import PIL.Image
-            os.makedirs(os.path.join(o.outdir, "forward_images"), exist_ok=True)
             PIL.Image.fromarray(fwds[j][0].permute(1, 2, 0).cpu().numpy(), "RGB").save(
-                os.path.join(o.outdir, "forward_images", f"{i:06d}_{seed:06d}.png"))
+                os.path.join(o.outdir, "forward_images", name(u)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,12 +25,16 @@ SMALL_B = UNetConfig(image_size=64, num_channels=32, num_res_blocks=2, channel_m
                      attention_resolutions="32", num_heads=2, num_head_channels=-1,
                      use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=True)
 
+# 256x256 with the ImageNet-256 block structure (6 levels, attention at 32/16/8 -> T = 1024 / 256 / 64) at 32 base channels
+SMALL_C = UNetConfig(image_size=256, num_channels=32, num_res_blocks=1, channel_mult=(), learn_sigma=True,
+                     attention_resolutions="32,16,8", num_heads=4, num_head_channels=32,
+                     use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False)
 
 
-def script(seed, shape, n_steps, sig0, neg_gamma_at=None):
+def script(seed, shape, n_steps, sig0, neg_gamma_at=None, sig_end=0.5):
     """A scripted alternation of time and space updates with seeded vectors (mimics the Heun call pattern)."""
     g = rng(seed)
-    sig = np.geomspace(sig0, 0.5, n_steps + 1)
+    sig = np.geomspace(sig0, sig_end, n_steps + 1)
     steps = []
     for i in range(n_steps):
         x = torch.randn(shape, generator=g, dtype=F64) * sig[i]
@@ -58,6 +62,14 @@ def smooth_image(size, seed):
     return torch.from_numpy(img[None].astype(np.float32))
 
 
+
+
+def solver256_measurement(name, x, mask=None, noise_seed=131):
+    """The measurement fed to the full-size solver fixtures (solver256.npz): built WITHOUT the operator, so that every
+    side regenerates it bit for bit - the sharp image itself (decimated for SR, masked for inpainting) plus 0.1 noise."""
+    y = x[..., ::4, ::4].clone() if name == "super_resolution" else x.clone()
+    y = y + 0.1 * randn(y.shape, noise_seed, torch.float32)
+    return y * mask if mask is not None else y
 
 
 def dense_case(seed, bs, d, n_steps=3):

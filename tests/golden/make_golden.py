@@ -74,7 +74,7 @@ from training.openai_util import create_model  # noqa: E402
 
 from oracle.unet_oracle import UNetConfig, seeded_state  # noqa: E402  (weights recipe + config only)
 sys.path.insert(0, HERE)
-from inputs import SMALL_A, SMALL_B, dense_case, dense_chain, randn, rng, script as _script, smooth_image  # noqa: E402
+from inputs import SMALL_A, SMALL_B, SMALL_C, solver256_measurement, dense_case, dense_chain, randn, rng, script as _script, smooth_image  # noqa: E402
 
 F64 = torch.float64
 
@@ -209,6 +209,150 @@ def gold_cov():
     save("covariance", **out)
 
 
+def gold_cov_trunc():
+    """a10: `0 < max_vector_count < k` (online_update_bfgs.py:233-245, 309-310) - the newest columns of the
+    sqrtm-mixed factors are kept and the other three representations are re-derived."""
+    tmp = tempfile.mkdtemp()
+    dv_full = torch.load(os.path.join(REF, "data/imagenet/dct_variance.pt"), weights_only=True)
+    dv16 = dv_full[:, :16, :16].contiguous()
+    torch.save(dv16, os.path.join(tmp, "dct_variance.pt"))
+    cases = [
+        ("id_d15_max1", "identity", (1, 15), {"max_vector_count": 1}, 5),
+        ("id_d15_max3", "identity", (1, 15), {"max_vector_count": 3}, 6),
+        ("dct16_max1", "dct_diagonal", (1, 3, 16, 16), {"max_vector_count": 1}, 5),
+        ("dct16_max3", "dct_diagonal", (1, 3, 16, 16), {"max_vector_count": 3}, 6),
+    ]
+    out = {"dct_variance16": dv16}
+    for ci, (tag, kind, shape, kw, n) in enumerate(cases):
+        d = int(np.prod(shape[1:]))
+        sig0 = 80.0
+        cov = _mk_cov(kind, d, sig0 ** 2, shape, tmp, **kw)
+        steps = _script(1100 + ci, shape, n, sig0, None)
+        probe = randn(shape, 2100 + ci)
+        out[f"{tag}__n"] = len(steps)
+        out[f"{tag}__meta"] = np.array(repr(dict(kind=kind, shape=shape, kw=kw, sigma0=sig0, only_cov=False,
+                                                   n_steps=n, neg=None, script_seed=1100 + ci, probe_seed=2100 + ci)))
+        for si, (what, a) in enumerate(steps):
+            pre = f"{tag}__{si}_"
+            if what == "time":
+                mean, score = cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+                out.update({pre + "kind": 0, pre + "mean": mean, pre + "new_score": score})
+            else:
+                cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+                out.update({pre + "kind": 1})
+            out[pre + "apply"] = cov.denoiser_cov_vector_dot(probe)
+            out[pre + "k"] = cov.vectors_denoiser_cov_u.shape[-1]
+            out[pre + "imag"] = max(float(cov.vectors_denoiser_cov_u.imag.abs().max()) if out[pre + "k"] else 0.0,
+                                    float(cov.vectors_denoiser_cov_v.imag.abs().max()) if out[pre + "k"] else 0.0)
+            if d <= 15:
+                for nm, m in zip(("C", "Ci", "H", "Hi"), cov.get_dense_matrices()):
+                    out[pre + nm] = m
+    save("covariance_trunc", **out)
+
+
+COV256_SUB = 8       # stored fields: every 8th DCT/pixel index per axis (3 x 32 x 32) + sum, sum of squares
+COV256_PAIRS = 16    # Heun-30 with the default thresholds ends at k = 16
+
+
+def gold_cov256():
+    """SURVEY 8(c) item 3 at full size: the reference's CovarianceHessianBFGSDCT at d = 196608 with the shipped
+    dct_variance.pt through a scripted sequence of 16 time + 16 space updates (k = 16, i.e. m = 32 columns in the real
+    layout).  After every space update: cov-apply of a seeded probe; after every time update: predicted mean / score."""
+    shape = (1, 3, 256, 256)
+    d = 3 * 256 * 256
+    sig0 = 80.0
+    cov = ref_cov.CovarianceHessianBFGSDCT(os.path.join(REF, "data/imagenet"), sig0 ** 2, d, dtype=torch.complex128,
+                                           use_precalculated_info=True)
+    steps = _script(1256, shape, COV256_PAIRS, sig0, None)
+    probe = randn(shape, 2256)
+    sub = (slice(None), slice(None), slice(None, None, COV256_SUB), slice(None, None, COV256_SUB))
+    out = {"meta": np.array(repr(dict(shape=shape, sigma0=sig0, n_steps=COV256_PAIRS, script_seed=1256, probe_seed=2256,
+                                      sub=COV256_SUB))), "n": len(steps)}
+
+    def rec(pre, t):
+        t = t.detach().double()
+        out[pre] = t[sub]
+        out[pre + "_sum"] = t.sum()
+        out[pre + "_sq"] = (t ** 2).sum()
+
+    import time
+    for si, (what, a) in enumerate(steps):
+        t0 = time.time()
+        pre = f"{si}_"
+        if what == "time":
+            mean, score = cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+            out[pre + "kind"] = 0
+            rec(pre + "mean", mean)
+            rec(pre + "new_score", score)
+        else:
+            cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+            out[pre + "kind"] = 1
+            rec(pre + "apply", cov.denoiser_cov_vector_dot(probe))
+        out[pre + "k"] = cov.vectors_denoiser_cov_u.shape[-1]
+        print(f"cov256 step {si} {what} k={out[pre + 'k']} {time.time() - t0:.1f}s", flush=True)
+    save("covariance256", **out)
+
+
+SOLVER256_SUB = 4
+SOLVER256_SIG_END = 4.0
+
+
+def gold_solver256():
+    """SURVEY 8(c) item 5 at full size: choose_solver(customcuda) for the four operators at 256x256 with the shipped DCT
+    prior after a scripted 3-pair covariance sequence, at two noise levels each (a loose-rtol and a tight-rtol solve)."""
+    out = {}
+    size = 256
+    shape = (1, 3, size, size)
+    d = 3 * size * size
+    x = smooth_image(size, 19)
+    records = []
+    orig_cg = ref_cg.cg
+
+    def rec_cg(*a, **k):
+        sol, info = orig_cg(*a, **k)
+        records.append((info["niter"], bool(info["optimal"]), float(info["residual_norm"]), k.get("rtol")))
+        return sol, info
+
+    ref_cm.torch_cg.cg = rec_cg
+    import time
+    # the script ends at sigma = 4: C is still O(10) against sigma_y^2 = 0.01, so the tight-rtol solves are long
+    steps = _script(1500, shape, 3, 80.0, None, SOLVER256_SIG_END)
+    for name in ("gaussian_blur", "motion_blur", "super_resolution", "inpainting"):
+        op = _operator(name, size, seed=14)
+        op.forward(x.clone(), noiseless=True)  # caches pre_calculated, which the solvers read (measurements.py:186)
+        y = solver256_measurement(name, x, op.mask if name == "inpainting" else None)
+        p = f"{name}_"
+        if name == "inpainting":
+            out[p + "mask"] = np.packbits(op.mask[0, 0].to(torch.uint8).numpy())
+        cov = ref_cov.CovarianceHessianBFGSDCT(os.path.join(REF, "data/imagenet"), 80.0 ** 2, d, dtype=torch.complex128,
+                                               use_precalculated_info=True)
+        for what, a in steps:
+            if what == "time":
+                cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+            else:
+                cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+        x0_mean = (x + 0.05 * randn(x.shape, 1600, torch.float32)).to(F64)
+        for tag, sigma_t in (("hi", 3.0), ("lo", 0.12)):
+            records.clear()
+            t0 = time.time()
+            mat = ref_cm.choose_solver(name, op, y, x0_mean, None, cov, "customcuda", 1.0, sigma_t=sigma_t)
+            q = f"{p}{tag}_"
+            out[q + "sigma_t"] = sigma_t
+            out[q + "mat_sub"] = mat[..., ::SOLVER256_SUB, ::SOLVER256_SUB]
+            out[q + "mat_sum"] = mat.double().sum()
+            out[q + "mat_sq"] = (mat.double() ** 2).sum()
+            out[q + "niter"] = records[0][0]
+            out[q + "optimal"] = records[0][1]
+            out[q + "resnorm"] = records[0][2]
+            out[q + "rtol"] = records[0][3]
+            print(f"solver256 {name} sigma_t={sigma_t} niter={records[0][0]} rtol={records[0][3]:.3g} "
+                  f"{time.time() - t0:.1f}s", flush=True)
+    out["meta"] = np.array(repr(dict(script_seed=1500, n_pairs=3, image_seed=19, noise_seed=131, x0_seed=1600,
+                                     op_seed=14, sub=SOLVER256_SUB, sig_end=SOLVER256_SIG_END)))
+    ref_cm.torch_cg.cg = orig_cg
+    save("solver256", **out)
+
+
 # ------------------------------------------------------------------ 3b. dense helpers (analytic cross-check, config 3)
 DENSE_CASES = [("d5", 11, 2, 5), ("d15", 12, 2, 15), ("d256", 13, 2, 256)]
 DENSE_ROWS = 64  # d = 256: every 64th row of each matrix is stored, plus matrix x probe products
@@ -334,12 +478,32 @@ def gold_solver():
 
 
 # ------------------------------------------------------------------ 6. whole trajectories (a1, a6)
-def gold_traj():
-    size = 64
+TRAJ_CASES_64 = [
+    ("gb_heun10", "gaussian_blur", "heun", 10, {}),
+    ("mb_heun10", "motion_blur", "heun", 10, {}),
+    ("sr_heun10", "super_resolution", "heun", 10, {}),
+    ("ip_euler20", "inpainting", "euler", 20, {}),
+    ("gb_heun10_nospace", "gaussian_blur", "heun", 10, {"do_space_updates": False}),
+    ("gb_heun10_readme", "gaussian_blur", "heun", 10, {"space_step_update_lower_threshold": 1000.0,
+                                                       "space_step_update_threshold": 5.0}),
+    ("gb_heun10_identity", "gaussian_blur", "heun", 10, {"image_base_covariance": "identity"}),
+    ("gb_heun30", "gaussian_blur", "heun", 30, {}),
+]
+# one full-size Heun-30 trajectory per operator (the BASELINE.json configurations' operators)
+TRAJ_CASES_256 = [
+    ("gb256_heun30", "gaussian_blur", "heun", 30, {}),
+    ("mb256_heun30", "motion_blur", "heun", 30, {}),
+    ("sr256_heun30", "super_resolution", "heun", 30, {}),
+    ("ip256_heun30", "inpainting", "heun", 30, {}),
+]
+TRAJ_SUB_256 = 4  # x_final is stored every 4th pixel per axis (+ sum / sum of squares / abs-max of the full field)
+
+
+def gold_traj(size=64, cfg=SMALL_A, unet_seed=11, cases=TRAJ_CASES_64, seed_base=40, name="trajectories", sub=1):
     tmp = tempfile.mkdtemp() + "/"
     dv_full = torch.load(os.path.join(REF, "data/imagenet/dct_variance.pt"), weights_only=True)
     torch.save(dv_full[:, :size, :size].contiguous(), os.path.join(tmp, "dct_variance.pt"))
-    net = ref_net(SMALL_A, 11)
+    net = ref_net(cfg, unet_seed)
     base = dict(conditioning_mechanism="online_covariance", cond_scaling=1.0, clip_x0_mean=False,
                 pigdm_posthoc_scaling=False, max_vector_count=100000, dataset_path=tmp,
                 image_base_covariance="dct_diagonal", pca_component_count=10,
@@ -347,17 +511,6 @@ def gold_traj():
                 project_to_diagonal=False, space_step_update_threshold=10.0,
                 space_step_update_lower_threshold=1.0, max_rtol=1.0, do_space_updates=True,
                 use_analytic_var_at_end=False, solver_type="customcuda", use_rtol_func=False, diffpir_lambda=10.0)
-    cases = [
-        ("gb_heun10", "gaussian_blur", "heun", 10, {}),
-        ("mb_heun10", "motion_blur", "heun", 10, {}),
-        ("sr_heun10", "super_resolution", "heun", 10, {}),
-        ("ip_euler20", "inpainting", "euler", 20, {}),
-        ("gb_heun10_nospace", "gaussian_blur", "heun", 10, {"do_space_updates": False}),
-        ("gb_heun10_readme", "gaussian_blur", "heun", 10, {"space_step_update_lower_threshold": 1000.0,
-                                                           "space_step_update_threshold": 5.0}),
-        ("gb_heun10_identity", "gaussian_blur", "heun", 10, {"image_base_covariance": "identity"}),
-        ("gb_heun30", "gaussian_blur", "heun", 30, {}),
-    ]
     trace, holder = [], {}
     orig_cg, orig_get_op, orig_choose = ref_cg.cg, ref_gc.get_operator, ref_gc.choose_conditioning_mechanism
 
@@ -395,26 +548,34 @@ def gold_traj():
     ref_cm.torch_cg.cg = rec_cg
     ref_gc.get_operator = rec_get_op
     ref_gc.choose_conditioning_mechanism = lambda name: Recorder
-    out = {"cfg": cfg_dict(SMALL_A), "unet_seed": 11,
-           "dct_variance64": dv_full[:, :size, :size].contiguous()}
+    out = {"cfg": cfg_dict(cfg), "unet_seed": unet_seed}
+    if size == 64:
+        out["dct_variance64"] = dv_full[:, :size, :size].contiguous()
     for ci, (tag, opname, solver, nsteps, over) in enumerate(cases):
-        x0 = smooth_image(size, 40 + ci)
-        noise = randn((1, 3, size, size), 50 + ci, torch.float32)
+        x0 = smooth_image(size, seed_base + ci)
+        noise = randn((1, 3, size, size), seed_base + 10 + ci, torch.float32)
         op_kw = dict(name=opname, device=torch.device("cpu"), sigma_s=0.1, kernel_size=61, intensity=1.0,
                      scale_factor=4, in_shape=(1, 3, size, size),
                      mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
                                "mask_prob_range": (0.6, 0.8), "image_size": size})
         trace.clear()
-        np.random.seed(60 + ci)
-        torch.manual_seed(60 + ci)
+        np.random.seed(seed_base + 20 + ci)
+        torch.manual_seed(seed_base + 20 + ci)
         import contextlib
         import io
+        import time
+        t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             x_final, _x_all, y = ref_gc.conditional_sampler(
                 net, noise, x0.clone(), op_kw, {}, num_steps=nsteps, sigma_min=0.002, sigma_max=80, rho=7,
                 solver=solver, **{**base, **over})
         p = tag + "__"
-        out.update({p + "seeds": np.array([40 + ci, 50 + ci]), p + "y": y, p + "x_final": x_final,
+        if sub > 1:  # full-size case: strided sample + moments of the final image
+            xf = x_final.detach().double()
+            out.update({p + "x_final_sum": xf.sum(), p + "x_final_sq": (xf ** 2).sum(), p + "x_final_absmax": xf.abs().max(),
+                        p + "x0_sub": x0[..., ::sub, ::sub], p + "secs": time.time() - t0})
+            x_final = x_final[..., ::sub, ::sub]
+        out.update({p + "seeds": np.array([seed_base + ci, seed_base + 10 + ci]), p + "y": y, p + "x_final": x_final,
                     p + "op": np.array(opname), p + "solver": np.array(solver), p + "num_steps": nsteps,
                     p + "over": np.array(repr(over)),
                     p + "niter": np.array([t["niter"] for t in trace]),
@@ -427,7 +588,12 @@ def gold_traj():
         print(tag, "calls", len(trace), "niter sum", int(np.sum(out[p + "niter"])), "k", out[p + "k"][-1],
               "cov-branch", int(np.sum(out[p + "branch_cov"])))
     ref_cm.torch_cg.cg, ref_gc.get_operator, ref_gc.choose_conditioning_mechanism = orig_cg, orig_get_op, orig_choose
-    save("trajectories", **out)
+    save(name, **out)
+
+
+def gold_traj256():
+    gold_traj(size=256, cfg=SMALL_C, unet_seed=13, cases=TRAJ_CASES_256, seed_base=240, name="trajectories256",
+              sub=TRAJ_SUB_256)
 
 
 # ------------------------------------------------------------------ 7. scalar-variance baselines
@@ -504,4 +670,5 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     for w in which:
         {"sigma": gold_sigma, "unet": gold_unet, "cov": gold_cov, "ops": gold_ops, "solver": gold_solver,
-         "traj": gold_traj, "dense": gold_dense, "baselines": gold_baselines}[w]()
+         "traj": gold_traj, "dense": gold_dense, "baselines": gold_baselines, "cov_trunc": gold_cov_trunc,
+         "cov256": gold_cov256, "solver256": gold_solver256, "traj256": gold_traj256}[w]()

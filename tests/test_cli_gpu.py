@@ -22,7 +22,8 @@ def test_cli_two_images(tmp_path):
     out = tmp_path / "out"
     gc.main([f"--outdir={out}", f"--dataset_path={data}", "--synthetic_weights=ffhq", "--num_steps=4",
              "--total_images=2", "--max_batch_size=2", "--operator_name=inpainting", "--inpainting_prob_lower=0.6",
-             "--inpainting_prob_upper=0.8", "--solver=euler"])
+             "--inpainting_prob_upper=0.8", "--solver=euler", "--conditioning_mechanism=online_covariance",
+             "--image_base_covariance=dct_diagonal"])
     for sub in ("images", "cond_images", "forward_images"):
         names = sorted(os.listdir(out / sub))
         assert names == ["000000_000000.png", "000001_000000.png"], (sub, names)

@@ -25,8 +25,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-# each case costs ~12 s of CPU-oracle UNet time; four of the seven run only with FH_FULL_TESTS=1
-TF_BASELINE_TAGS = BASELINE_TAGS if os.environ.get("FH_FULL_TESTS") == "1" else ["pigdm_gb", "dps_sr", "peng_analytic_gb"]
+TF_BASELINE_TAGS = BASELINE_TAGS  # each case costs ~12 s of CPU-oracle UNet time
 
 
 @pytest.mark.parametrize("tag", TF_BASELINE_TAGS)

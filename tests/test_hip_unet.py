@@ -334,7 +334,6 @@ def test_unet_ffhq256_hip_vs_torch_backend(dev):
     assert rel(outs[0][1], outs[1][1]) < 2e-3
 
 
-@pytest.mark.skipif(os.environ.get("FH_FULL_TESTS") != "1", reason="552 M parameters, ~1 min: runs with FH_FULL_TESTS=1")
 def test_unet_imagenet256_hip_vs_torch_backend(dev):
     """The ImageNet-256 architecture (configs[0], [2], [4]: 42 ResBlocks, attention at 32 / 16 / 8 with T up to 1024) at
     full size, batch 2: forward and input-VJP of the HIP backend against the PyTorch-ROCm backend, same seeded weights."""

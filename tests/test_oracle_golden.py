@@ -77,8 +77,10 @@ def _cov_cases(g):
     return sorted({k.split("__")[0] for k in g.files if "__meta" in k})
 
 
-def test_covariance_sequences(gold, tmp_path):
-    g = gold("covariance")
+@pytest.mark.parametrize("fixture", ["covariance", "covariance_trunc"])
+def test_covariance_sequences(gold, tmp_path, fixture):
+    """covariance_trunc: `0 < max_vector_count < k` (online_update_bfgs.py:233-245, 309-310)."""
+    g = gold(fixture)
     torch.save(T(g["dct_variance16"]), tmp_path / "dct_variance.pt")
     for tag in _cov_cases(g):
         meta = eval(str(g[f"{tag}__meta"]))
@@ -211,17 +213,86 @@ def test_solver_calls(gold, name, tmp_path):
 
 
 # ---------------------------------------------------------------- a1, a6
+def _sub_check(got, g, key, sub, tol):
+    """a full-size field against its stored strided sample + sum + sum of squares"""
+    got = T(got).double()
+    ref = T(g[key]).double()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got[..., ::sub, ::sub] - ref).abs().max()) < tol * scale, key
+    assert abs(float(got.sum()) - float(g[key + "_sum"])) < tol * max(1.0, float(got.abs().sum())), key
+    assert abs(float((got ** 2).sum()) - float(g[key + "_sq"])) < 10 * tol * max(1.0, float(g[key + "_sq"])), key
+
+
+def test_covariance256_full_size(gold):
+    """d = 196608 with the shipped dct_variance.pt, 16 time + 16 space updates (k = 16)."""
+    import os
+    g = gold("covariance256")
+    meta = eval(str(g["meta"]))
+    shape, sub = meta["shape"], meta["sub"]
+    d = int(np.prod(shape[1:]))
+    data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "free-hunch_amd", "data")
+    cov = fo.make_covariance("dct_diagonal", data, meta["sigma0"] ** 2, d)
+    steps = inputs.script(meta["script_seed"], shape, meta["n_steps"], meta["sigma0"], None)
+    probe = inputs.randn(shape, meta["probe_seed"])
+    for si, (what, a) in enumerate(steps):
+        pre = f"{si}_"
+        if what == "time":
+            mean, score = cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+            _sub_check(mean, g, pre + "mean", sub, 1e-9)
+            _sub_check(score, g, pre + "new_score", sub, 1e-9)
+        else:
+            cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+            _sub_check(cov.denoiser_cov_vector_dot(probe), g, pre + "apply", sub, 1e-9)
+        assert cov.k == int(g[pre + "k"])
+    assert cov.k == 16
+
+
+@pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
+def test_solver_calls_256(gold, name):
+    """choose_solver(customcuda) at 256 x 256 (reference outputs in solver256.npz)."""
+    import os
+    g = gold("solver256")
+    meta = eval(str(g["meta"]))
+    size, sub = 256, meta["sub"]
+    shape, d = (1, 3, size, size), 3 * size * size
+    data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "free-hunch_amd", "data")
+    x = inputs.smooth_image(size, meta["image_seed"])
+    p = f"{name}_"
+    mask = None
+    if name == "inpainting":
+        mask = torch.from_numpy(np.unpackbits(g[p + "mask"])[: size * size].reshape(1, 1, size, size).copy())
+    op = _mk_op(name, size, {p + "mask": mask} if mask is not None else None, p)
+    op.forward(x.clone())  # caches pre_calculated
+    y = inputs.solver256_measurement(name, x, op.mask if name == "inpainting" else None, meta["noise_seed"])
+    cov = fo.make_covariance("dct_diagonal", data, 80.0 ** 2, d)
+    for what, a in inputs.script(meta["script_seed"], shape, meta["n_pairs"], 80.0, sig_end=meta.get("sig_end", 0.5)):
+        if what == "time":
+            cov.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+        else:
+            cov.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+    x0_mean = (x + 0.05 * inputs.randn(x.shape, meta["x0_seed"], torch.float32)).to(F64)
+    for lab in ("hi", "lo"):
+        q = f"{p}{lab}_"
+        info = []
+        mat = fo.solve_mat(op, y, x0_mean, cov, 1.0, float(g[q + "sigma_t"]), info)
+        ref = T(g[q + "mat_sub"]).double()
+        scale = max(1.0, float(ref.abs().max()))
+        if same_host_arithmetic(gold):
+            assert info[0]["niter"] == int(g[q + "niter"]), (q, info[0])
+            assert float((mat[..., ::sub, ::sub].double() - ref).abs().max()) < 1e-6 * scale, q
+        else:
+            assert abs(info[0]["niter"] - int(g[q + "niter"])) <= 0.1 * int(g[q + "niter"]) + 1, (q, info[0])
+
+
 def _traj_cases(g):
     return sorted({k.split("__")[0] for k in g.files if "__" in k})
 
 
-def run_oracle_traj(g, tag, tmp_path):
+def run_oracle_traj(g, tag, tmp_path, size=64, cfg=inputs.SMALL_A):
     p = tag + "__"
     over = eval(str(g[p + "over"]))
     opname, solver, nsteps = str(g[p + "op"]), str(g[p + "solver"]), int(g[p + "num_steps"])
     s_img, s_noise = (int(v) for v in g[p + "seeds"])
-    size = 64
-    cfg = inputs.SMALL_A
     net = fo.LinearPrecond(uo.OracleUNet(cfg, uo.seeded_state(cfg, int(g["unet_seed"]))))
     op = _mk_op(opname, size, g, p)
     x0 = inputs.smooth_image(size, s_img)
@@ -251,6 +322,26 @@ def test_trajectory(gold, tag, tmp_path):
         assert [int(t["branch"] == "cov") for t in tr] == list(g[p + "branch_cov"])
         assert [t["niter"] for t in tr] == list(g[p + "niter"])
         assert maxabs(x, g[p + "x_final"]) < 1e-3
+
+
+def test_trajectory_256_super_resolution(gold):
+    """a full-size (256 x 256, Heun-30, shipped DCT prior) trajectory recorded from the reference's
+    `conditional_sampler`.  SR x4 is the well-conditioned operator (n = d / 16), so the oracle reproduces the recording
+    call by call; the other three full-size recordings (blur, motion blur, inpainting: ~95 s each on 8 cores) are
+    replayed by the HIP path in tests/test_hip_parity256.py."""
+    import os
+    g = gold("trajectories256")
+    tag = "sr256_heun30"
+    data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "free-hunch_amd", "data")
+    x, mech = run_oracle_traj(g, tag, data, size=256, cfg=inputs.SMALL_C)
+    p = tag + "__"
+    tr = mech.trace
+    assert [t["k"] for t in tr] == list(g[p + "k"])
+    assert np.allclose([t["sigma"] for t in tr], g[p + "sigma"], rtol=2e-7, atol=0)
+    assert [int(t["branch"] == "cov") for t in tr] == list(g[p + "branch_cov"])
+    assert [t["niter"] for t in tr] == list(g[p + "niter"])
+    assert maxabs(x[..., ::4, ::4], g[p + "x_final"]) < 1e-3
+    assert abs(float(x.double().sum()) - float(g[p + "x_final_sum"])) < 1e-3 * x.numel() ** 0.5
 
 
 # ---------------------------------------------------------------- dense helpers (analytic cross-check; config 3)
