@@ -23,7 +23,7 @@ class FhProblem(C.Structure):
 
 
 FH_MAX_BATCH = 16
-FH_EINVAL, FH_ESIZE = -1, -2  # include/fh_hip.h
+FH_EINVAL, FH_ESIZE, FH_ESYNC = -1, -2, -3  # include/fh_hip.h
 
 
 class FhBatch(C.Structure):
@@ -46,6 +46,8 @@ _SIGS = {
     "fh_version": ([], C.c_int),
     "fh_context_create": ([C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int], C.c_int),
     "fh_context_destroy": ([C.c_void_p], C.c_int),
+    "fh_context_set_exclusive": ([C.c_void_p, C.c_int], C.c_int),
+    "fh_context_status": ([C.c_void_p, C.c_void_p], C.c_int),
     "fh_dct2d": ([C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_apply": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_apply_batched": ([C.c_void_p, C.POINTER(FhBatch), C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
@@ -157,6 +159,15 @@ class Context:
         if key not in cls._cache:
             cls._cache[key] = cls(S, planes, m_cap)
         return cls._cache[key]
+
+    def set_exclusive(self, flag):
+        """Declare that no other grid-synchronising kernel shares the GPU with this context's stream (include/fh_hip.h):
+        the covariance apply then reads the factor base once instead of twice."""
+        check(self.lib.fh_context_set_exclusive(self.h, int(bool(flag))), "fh_context_set_exclusive")
+
+    def status(self):
+        """Raises if a single-sweep covariance apply of this context timed out since the last call."""
+        check(self.lib.fh_context_status(self.h, stream()), "fh_context_status")
 
     # thin typed wrappers ------------------------------------------------------------------
     def dct2d(self, x, out=None, inverse=False):

@@ -136,7 +136,8 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
     return operator._conv(sol, stride=prob.stride, adjoint=True)
 
 
-def solve_customcuda_batched(operators, ys, x0_means, covariance_models, max_rtol, sigma_t, infos_out=None):
+def solve_customcuda_batched(operators, ys, x0_means, covariance_models, max_rtol, sigma_t, infos_out=None,
+                             exclusive=False):
     """The same solve for B independent images in ONE kernel sequence (`fh_cg_solve_batched`): all images share the
     operator type / taps / noise level and the number of factor columns (they advance in lock-step), each has its own
     covariance state, measurement and iteration count.  Returns mat [B,3,S,S] float64."""
@@ -150,6 +151,9 @@ def solve_customcuda_batched(operators, ys, x0_means, covariance_models, max_rto
     # scratch sized for the whole batch; one context per lock-step GROUP (keyed by the group's first image slot), so
     # that equal-sized groups running concurrently from different host threads never share CG vectors or graph caches
     ctx = _lib.Context.get(S, 3 * B, 0, slot=5000 + 64 * int(getattr(op0, "ctx_slot", 0)) + B)
+    # `exclusive`: nothing else synchronises across workgroups on this GPU while the solve runs (the lock-step sampler
+    # has joined its per-image streams) -> the covariance apply inside CG reads each factor base once, not twice
+    ctx.set_exclusive(exclusive)
     prob, keep = _problem(op0, cov0, _sigma_y2(op0))
     per = _lib.FhBatch()
     per.nimg = B

@@ -73,4 +73,8 @@ struct fh_context {
   fh_graph_entry graphs[4];
   uint64_t graph_clock;
   int graphs_disabled;   // set when stream capture is not possible on the caller's stream (e.g. the null stream)
+  unsigned int* sync;    // k_rep_fused: per image {arrive, depart} counters on their own lines + one error word
+  int num_cus;
+  int exclusive;         // the caller guarantees that no other grid-synchronising kernel shares the GPU with this context
+  int fused_disabled;    // set after a k_rep_fused time-out was reported
 };

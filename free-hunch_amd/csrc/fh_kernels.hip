@@ -295,6 +295,7 @@ __global__ __launch_bounds__(1024) void k_rep_coef(fh_batch per, const double* _
 #pragma unroll
       for (int g = 0; g < 32; ++g) sum += red[g][jj];
       t[j] = sum;
+      coef[FH_MAX_COLS + j] = sum;  // t = B^T (r.*z) itself (read by the closed-form BFGS inverse of the space update)
     }
     __syncthreads();
   }
@@ -331,13 +332,26 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
   __syncthreads();
   const int64_t blk = (int64_t)gridDim.x - 1 - blockIdx.x;  // reverse sweep
   for (int64_t i0 = blk * kDotRows + 2 * tid; i0 < (blk + 1) * kDotRows && i0 + 1 < d; i0 += 512) {
-    double2 acc = make_double2(0.0, 0.0);
-    for (int j = 0; j < m; ++j) {
-      const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
-      const double cj = c[j];
-      acc.x = fma(b.x, cj, acc.x);
-      acc.y = fma(b.y, cj, acc.y);
+    // canonical summation order of (B c)_i, shared with the single-sweep kernel k_rep_fused (whose 8 waves each own the
+    // columns j = w (mod 8)): eight chains over j = w, w + 8, ... then the chains added in the order w = 0 .. 7
+    double2 ch[8];
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) ch[w8] = make_double2(0.0, 0.0);
+    for (int j0 = 0; j0 < m; j0 += 8) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const int j = j0 + w8;
+        if (j < m) {
+          const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
+          const double cj = c[j];
+          ch[w8].x = fma(b.x, cj, ch[w8].x);
+          ch[w8].y = fma(b.y, cj, ch[w8].y);
+        }
+      }
     }
+    double2 acc = ch[0];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) acc.x += ch[w8].x, acc.y += ch[w8].y;
     const double2 zz = *reinterpret_cast<const double2*>(z + i0);
     const double2 dd = *reinterpret_cast<const double2*>(D + i0);
     double2 o;
@@ -351,6 +365,207 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-sweep representation apply (k_rep_fused): B is read ONCE.
+// The two-pass form above is bound by its second sweep of the factor base (2 x 8 d m bytes; the base of 8 lock-step
+// images, 400 MB, does not fit the 256 MB Infinity Cache).  Here a 512-thread workgroup keeps its 768-row x m slice of
+// B in REGISTERS (wave w owns the columns j = w (mod 8): 6 row pairs x MC columns = 48 / 96 doubles per lane at
+// m <= 32 / 64) between the reduction t = B^T (r.*z) and the product B (M t):
+//   phase 1  slice -> registers, block partials of t (same per-column arithmetic as k_rep_dots), sc1 stores
+//   arrive   every wave drains its stores, workgroup barrier, one relaxed agent-scope add on the image's counter
+//   wait     thread 0 polls the counter with relaxed sc1 loads + s_sleep (BOUNDED: on time-out the error word of the
+//            context is set and the workgroup leaves - every wave reaches its exit)
+//   phase 2  every workgroup re-reduces the nb x m partials with sc1 loads (64 KB from L2 / fabric; same fixed order
+//            as k_rep_coef), forms c = M t, multiplies its register slice, adds the 8 per-wave chains through LDS in the
+//            canonical order and writes out = D.*z + r.*(B c)
+//   depart   the last workgroup to finish reading the partials resets the image's two counters
+// The hand-off follows the MI355X guide's measured counter form: sc1 (write-through) stores -> s_waitcnt vmcnt(0) in
+// every storing wave -> workgroup barrier -> one lane's agent-scope atomic add; consumer: relaxed sc1 poll by one wave,
+// workgroup barrier, sc1 loads of every handed-off byte.  No fence, no placement assumption.
+// Residency: images are dispatched in order (blockIdx.z slowest), an image's nb <= #CU workgroups fit the chip at once
+// (1 or 2 workgroups per CU by register budget) and finished workgroups never wait on later images, so every counter
+// completes PROVIDED no other grid-synchronising kernel runs concurrently - the launcher takes this path only on a
+// context the caller declared exclusive (fh_context_set_exclusive); everything else keeps the two-pass kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFusedSpinLimit = 1 << 21;  // x s_sleep(2) ~ 64 clocks: ~ 0.1 s before a workgroup gives up
+constexpr int kSyncStride = 64;           // uint32 per image: arrive counter at +0, depart counter at +32 (own 128-B lines)
+
+template <int MC>
+__global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per, const double* __restrict__ z,
+                                                                    double* __restrict__ out, double* __restrict__ partial,
+                                                                    unsigned int* __restrict__ sync, int64_t d, int m,
+                                                                    int ldm, const fh_cg_state* __restrict__ states) {
+  const int img = blockIdx.z;
+  IMG_GUARD(states, img);
+  const double* __restrict__ B = per.B[img];
+  const double* __restrict__ r = per.r[img];
+  const double* __restrict__ D = per.D[img];
+  const double* __restrict__ M = per.M[img];
+  z += (int64_t)img * d;
+  out += (int64_t)img * d;
+  partial += (int64_t)img * kPartialRows * FH_MAX_COLS;
+  unsigned int* arrive = sync + img * kSyncStride;
+  unsigned int* depart = arrive + 32;
+  unsigned int* err = sync + FH_MAX_BATCH * kSyncStride;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nb = gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * kDotRows + 2 * lane;  // d is a multiple of kDotRows on this path
+  constexpr int kIter = kDotRows / 128;
+
+  __shared__ __align__(16) double psum[8][kDotRows];  // per-wave chains of (B c) over the workgroup's rows
+  __shared__ double red[32][33];
+  __shared__ double tsh[64], csh[64];
+  __shared__ int ok_s;
+
+  // ---- phase 1: r.*z of the workgroup's rows goes through LDS (every wave needs all of it; holding it in registers next
+  // to the slice would spill at the 128-VGPR budget of two workgroups per CU)
+  double* rzs = &psum[0][0];
+  if (tid < kDotRows / 2) {
+    const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
+    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
+    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+    *reinterpret_cast<double2*>(rzs + 2 * tid) = make_double2(zz.x * rr.x, zz.y * rr.y);
+  }
+  double2 breg[MC][kIter];
+#pragma unroll
+  for (int q = 0; q < MC; ++q) {
+    const int j = w + 8 * q;  // wave-uniform
+    if (j < m) {
+      const double* bp = B + (int64_t)j * d + r0;
+#pragma unroll
+      for (int it = 0; it < kIter; ++it) breg[q][it] = *reinterpret_cast<const double2*>(bp + it * 128);
+    } else {
+#pragma unroll
+      for (int it = 0; it < kIter; ++it) breg[q][it] = make_double2(0.0, 0.0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MC; ++q) {
+    double acc = 0.0;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const double2 rz = *reinterpret_cast<const double2*>(rzs + it * 128 + 2 * lane);
+      acc = fma(breg[q][it].x, rz.x, fma(breg[q][it].y, rz.y, acc));
+    }
+    const double v = wave_sum(acc);
+    const int j = w + 8 * q;
+    if (lane == 0 && j < m)
+      __hip_atomic_store(partial + (int64_t)blockIdx.x * FH_MAX_COLS + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::: "memory");  // re-read r.*z from LDS for the next column instead of keeping it live
+  }
+  // ---- arrive + wait
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1, spins = 0;
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nb) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kFusedSpinLimit) {
+        ok = 0;
+        break;
+      }
+    }
+    if (!ok) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok_s = ok;
+  }
+  __syncthreads();
+  if (!ok_s) return;  // uniform: every wave of the workgroup leaves
+
+  // ---- phase 2a: t = sum of the block partials, in k_rep_coef's order: row group rg = 0..31 adds the blocks
+  // rg, rg + 64, ... into one chain and rg + 32, rg + 96, ... into a second one.  The 16 sc1 loads of a thread are issued
+  // back to back (inline asm: the compiler would wait after every atomic load) and drained by ONE s_waitcnt that the
+  // results are tied to.
+  const int jj = tid & 31, rg2 = tid >> 5;
+  for (int j0 = 0; j0 < m; j0 += 32) {
+    const int j = j0 + jj;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // scalar base + 32-bit lane offset: one address VGPR per load keeps the batch inside the 128-VGPR budget
+      double v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = rg2 + 16 * h + 32 * i;
+        v[i] = 0.0;
+        if (j < m && b < nb) {
+          const unsigned int off = (unsigned int)((b * FH_MAX_COLS + j) * (int)sizeof(double));
+          asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v[i]) : "v"(off), "s"(partial) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                   :
+                   : "memory");
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) s0 += v[i], s1 += v[i + 1];
+      red[rg2 + 16 * h][jj] = s0 + s1;
+    }
+    __syncthreads();
+    if (rg2 == 0 && j < m) {
+      double sum = 0.0;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) sum += red[g][jj];
+      tsh[j] = sum;
+    }
+    __syncthreads();
+  }
+  // every partial this workgroup needs has been read: depart; the last one re-arms the image's counters for the next launch
+  if (tid == 0) {
+    const unsigned int prev = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)nb - 1u) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- phase 2b: c = M t (32 threads per row, as k_rep_coef)
+  for (int q0 = 0; q0 < m; q0 += 16) {
+    const int rowi = q0 + rg2;
+    double sum = 0.0;
+    if (rowi < m)
+      for (int l = jj; l < m; l += 32) sum = fma(M[(int64_t)rowi * ldm + l], tsh[l], sum);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 8, 64);
+    sum += __shfl_xor(sum, 16, 64);
+    if (rowi < m && jj == 0) csh[rowi] = sum;
+  }
+  __syncthreads();
+  // ---- phase 2c: this wave's chain over its columns, from registers
+  {
+    double cq[MC];
+#pragma unroll
+    for (int q = 0; q < MC; ++q) cq[q] = (w + 8 * q < m) ? csh[w + 8 * q] : 0.0;
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      double2 p = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int q = 0; q < MC; ++q) {
+        p.x = fma(breg[q][it].x, cq[q], p.x);
+        p.y = fma(breg[q][it].y, cq[q], p.y);
+      }
+      *reinterpret_cast<double2*>(&psum[w][it * 128 + 2 * lane]) = p;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2d: out = D.*z + r.*(chains added in the order w = 0 .. 7)
+  if (tid < kDotRows / 2) {
+    double2 acc = *reinterpret_cast<const double2*>(&psum[0][2 * tid]);
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) {
+      const double2 p = *reinterpret_cast<const double2*>(&psum[w8][2 * tid]);
+      acc.x += p.x, acc.y += p.y;
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
+    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
+    const double2 dd = *reinterpret_cast<const double2*>(D + i0);
+    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+    *reinterpret_cast<double2*>(out + i0) = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
+  }
+}
+
 static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const double* z, double* out, int64_t d,
                             int m, const fh_cg_state* states, hipStream_t st) {
   if (m < 0 || m > FH_MAX_COLS || (d & 1) || per.nimg < 1 || per.nimg > ctx->nimg_max) return FH_ESIZE;
@@ -361,12 +576,24 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
   // TB/s): same order 2.75, reverse order 2.97; splitting the batch into cache-sized groups of 4 (each group both
   // passes back to back) 2.80 - the extra dependent launches cost more than the additional hits return.
   const unsigned Z = (unsigned)per.nimg;
+  if (out != nullptr && m > 0 && m <= 64 && ctx->exclusive && !ctx->fused_disabled && d % kDotRows == 0 && nb <= ctx->num_cus &&
+      nb <= 256) {
+    if (m <= 32)
+      hipLaunchKernelGGL((k_rep_fused<4>), dim3(nb, 1, Z), dim3(512), 0, st, per, z, out, ctx->partial, ctx->sync, d, m, ldm,
+                         states);
+    else
+      hipLaunchKernelGGL((k_rep_fused<8>), dim3(nb, 1, Z), dim3(512), 0, st, per, z, out, ctx->partial, ctx->sync, d, m, ldm,
+                         states);
+    FH_LAUNCH_CHECK();
+    return 0;
+  }
   if (m > 0) {
     hipLaunchKernelGGL(k_rep_dots, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
     hipLaunchKernelGGL(k_rep_coef, dim3(1, 1, Z), dim3(1024), 0, st, per, (const double*)ctx->partial, nb, ldm, m,
                        ctx->coef, states);
   }
-  hipLaunchKernelGGL(k_rep_apply2, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m, states);
+  if (out != nullptr)  // out == null: only t = B^T (r.*z) and c = M t are wanted (left in ctx->coef[FH_MAX_COLS..] / [0..])
+    hipLaunchKernelGGL(k_rep_apply2, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m, states);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -390,12 +617,25 @@ __global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, co
   if (rx != nullptr) ry[i] = rx[i] / v;
 }
 
+// forward time shift of a representation and of its inverse: D <- D / (1 + s D), r <- r / (1 + s D), Dinv <- Dinv + s
+__global__ __launch_bounds__(256) void k_forward_diag(double* __restrict__ D, double* __restrict__ r,
+                                                      double* __restrict__ Dinv, double s, int64_t d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= d) return;
+  const double e = 1.0 / fma(s, D[i], 1.0);
+  D[i] *= e;
+  r[i] *= e;
+  Dinv[i] += s;
+}
+
 constexpr int kGramRowBlocks = 512;  // 384 rows each at d = 196608: two workgroups per CU
 constexpr int kGT = 64;  // Gram tile edge and row-chunk length
 
+// fwd = 0: weights rx^2 / Dx (Woodbury inverse of the representation); fwd = 1: rx^2 / (1 + fshift Dx) (forward time
+// shift of the representation itself, see cov_shift_forward)
 __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, const double* __restrict__ rx,
                                               const double* __restrict__ Dx, double* __restrict__ gpartial,
-                                              int64_t d, int m, int ntiles) {
+                                              int64_t d, int m, int ntiles, int fwd, double fshift) {
   __shared__ double As[kGT][kGT + 1];  // [row i][col of tile a], weighted
   __shared__ double Bs[kGT][kGT + 1];  // [row i][col of tile b]
   // decode tile pair
@@ -430,7 +670,7 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, cons
     // phase was measured slower: the allocator then needs > 256 VGPRs and the kernel drops to one workgroup per CU.)
     const int64_t gi = c0 + row;
     const bool rok = gi < r1;
-    const double wgt = rok ? rx[gi] * rx[gi] / Dx[gi] : 0.0;
+    const double wgt = rok ? rx[gi] * rx[gi] / (fwd ? fma(fshift, Dx[gi], 1.0) : Dx[gi]) : 0.0;
     double va[16], vb[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -644,6 +884,54 @@ __global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__
   }
 }
 
+constexpr int kWbMaxCols = 64;  // = kWbMax below: the device-side m x m algebra handles up to 64 columns
+
+// part[b] = sum over block b of a^2 .* w   (de^T D^-1 de of the closed-form BFGS inverse)
+__global__ __launch_bounds__(256) void k_wnorm_partial(const double* __restrict__ a, const double* __restrict__ w,
+                                                       double* __restrict__ part, int64_t n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(a[i] * a[i], w[i], s);
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_copy_small(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+// Inverse covariance after a BFGS pair, in closed form (no inversion, no Gram):
+//   C'^-1 = (I - g dx de^T) C^-1 (I - g de dx^T) + g dx dx^T,   g = 1 / (dx.de)
+// In the coordinates of the shared base (columns 0..mc-1 old, mc = de / r, mc+1 = C dx / r; C^-1 = 1/D + Wi Mi Wi^T with
+// Wi = (r / D) .* B):  dx = Wi' a,  C^-1 de = Wi' b  with  a = [-M t; 0; 1],  b = [Mi s; 1; 0],  t = W^T dx,  s = Wi^T de, so
+//   Mi' = pad(Mi) - g (a b^T + b a^T) + (g^2 rho + g) a a^T,   rho = de^T C^-1 de = de^T D^-1 de + s^T Mi s.
+// The generic Woodbury route passes through the singular matrix C - v v^T (v = C dx / sqrt(dx^T C dx)) and loses
+// cond(I + G M) ~ 1e9 of the 1e16 at d = 196608 with the DCT prior; this form has no cancellation.
+// scal: [0] dx.de, [2] de^T D^-1 de;  cC = M t (mc);  sCi = s, cCi = Mi s (mc).  One workgroup.
+__global__ __launch_bounds__(256) void k_bfgs_inverse_commit(const double* __restrict__ scal, const double* __restrict__ cC,
+                                                             const double* __restrict__ sCi, const double* __restrict__ cCi,
+                                                             double* __restrict__ Mi, int ld, int mc) {
+  __shared__ double a[kWbMaxCols + 2], b[kWbMaxCols + 2];
+  __shared__ double rho_s;
+  const int tid = threadIdx.x, n = mc + 2;
+  for (int j = tid; j < n; j += 256) {
+    a[j] = j < mc ? -cC[j] : (j == mc ? 0.0 : 1.0);
+    b[j] = j < mc ? cCi[j] : (j == mc ? 1.0 : 0.0);
+  }
+  if (tid == 0) {
+    double rho = scal[2];
+    for (int j = 0; j < mc; ++j) rho = fma(sCi[j], cCi[j], rho);  // fixed order
+    rho_s = rho;
+  }
+  __syncthreads();
+  const double g = 1.0 / scal[0], k2 = fma(g * g, rho_s, g);
+  for (int i = tid; i < n * n; i += 256) {
+    const int r = i / n, c = i % n;
+    const double old = (r < mc && c < mc) ? Mi[(int64_t)r * ld + c] : 0.0;
+    Mi[(int64_t)r * ld + c] = old - g * (a[r] * b[c] + b[r] * a[c]) + k2 * a[r] * a[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Circular convolution with a sparse tap list.
 //   k_conv_tile   : stride-1 output grid (blur, blur^T, and blur^T of a zero-inserted LR image):
@@ -757,8 +1045,10 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 constexpr int kWbMax = 64;
 
+// Mdst = sym( sign * Msrc (I + alpha G Msrc)^-1 ).  (alpha, sign) = (1, -1): Woodbury inverse; (s, +1): forward shift.
 __global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict__ Msrc, int lds_, const double* __restrict__ G,
-                                                        int ldg, double* __restrict__ Mdst, int ldd, int m) {
+                                                        int ldg, double* __restrict__ Mdst, int ldd, int m, double alpha,
+                                                        double sign) {
   extern __shared__ __align__(16) double wb[];
   const int w = 2 * m + 1;          // row pitch of the augmented matrix (odd: conflict-free column walks)
   double* aug = wb;                 // [m][w]   left: A^T, right: -Msrc^T
@@ -770,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict
   for (int i = tid; i < m * m; i += 256) {
     const int r = i / m, c = i % m;
     Ms[r * (m + 1) + c] = Msrc[(int64_t)r * lds_ + c];
-    Gs[r * (m + 1) + c] = G[(int64_t)r * ldg + c];
+    Gs[r * (m + 1) + c] = alpha * G[(int64_t)r * ldg + c];
   }
   __syncthreads();
   // A = I + G Msrc;  aug[r][c] = A^T[r][c] = A[c][r];  aug[r][m + c] = -Msrc^T[r][c] = -Msrc[c][r]
@@ -779,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict
     double a = r == c ? 1.0 : 0.0;
     for (int k = 0; k < m; ++k) a = fma(Gs[c * (m + 1) + k], Ms[k * (m + 1) + r], a);
     aug[r * w + c] = a;
-    aug[r * w + m + c] = -Ms[c * (m + 1) + r];
+    aug[r * w + m + c] = sign * Ms[c * (m + 1) + r];
   }
   __syncthreads();
   for (int k = 0; k < m; ++k) {
@@ -1234,6 +1524,14 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->tmp_img, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS * c->nimg_max));
   FH_CHECK(hipMalloc(&c->gpartial, sizeof(double) * c->gpartial_elems));
+  FH_CHECK(hipMalloc(&c->sync, sizeof(unsigned int) * (FH_MAX_BATCH * kSyncStride + 32)));
+  FH_CHECK(hipMemset(c->sync, 0, sizeof(unsigned int) * (FH_MAX_BATCH * kSyncStride + 32)));
+  {
+    int dev = 0, cus = 0;
+    FH_CHECK(hipGetDevice(&dev));
+    FH_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    c->num_cus = cus;
+  }
   FH_CHECK(hipMalloc(&c->coef, sizeof(double) * 2 * FH_MAX_COLS * c->nimg_max));
   FH_CHECK(hipMemset(c->coef, 0, sizeof(double) * 2 * FH_MAX_COLS));
   FH_CHECK(hipMalloc(&c->cg_r, sizeof(double) * nimg));
@@ -1254,7 +1552,7 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
 int fh_context_destroy(fh_context* c) {
   if (c == nullptr) return 0;
   void* bufs[] = {c->basis, c->basis_t, c->tmp_img, c->partial, c->gpartial, c->coef, c->cg_r,
-                  c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state};
+                  c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state, c->sync};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& g : c->graphs)
@@ -1267,6 +1565,27 @@ int fh_context_destroy(fh_context* c) {
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   delete c;
   return 0;
+}
+
+int fh_context_set_exclusive(fh_context* ctx, int exclusive) {
+  if (!ctx) return FH_EINVAL;
+  ctx->exclusive = exclusive ? 1 : 0;
+  return 0;
+}
+
+int fh_context_status(fh_context* ctx, void* stream) {
+  if (!ctx) return FH_EINVAL;
+  unsigned int flag = 0;
+  FH_CHECK(hipMemcpyAsync(&flag, ctx->sync + FH_MAX_BATCH * kSyncStride, sizeof(flag), hipMemcpyDeviceToHost,
+                          (hipStream_t)stream));
+  FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (flag == 0) return 0;
+  // a single-sweep apply timed out waiting for its peers (another grid-synchronising kernel shared the GPU): its output
+  // is invalid.  Re-arm the counters, keep this context on the two-pass kernels and report.
+  ctx->fused_disabled = 1;
+  FH_CHECK(hipMemsetAsync(ctx->sync, 0, sizeof(unsigned int) * (FH_MAX_BATCH * kSyncStride + 32), (hipStream_t)stream));
+  FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  return FH_ESYNC;
 }
 
 int fh_dct2d(fh_context* ctx, const double* in, double* out, int planes, int inverse, void* stream) {
@@ -1307,7 +1626,7 @@ int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B
     const int npairs = ntiles * (ntiles + 1) / 2;
     if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems) return FH_ESIZE;
     hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, st, B, rx, (const double*)Dx,
-                       ctx->gpartial, d, m, ntiles);
+                       ctx->gpartial, d, m, ntiles, 0, 0.0);
     hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
                        ntiles, m, G, ldg);
   } else {
@@ -1361,8 +1680,16 @@ int fh_space_commit_dev(fh_context* ctx, const double* de, const double* cdx, co
   return 0;
 }
 
+static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
+                        int m, double alpha, double sign, void* stream);
+
 int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
                       int m, void* stream) {
+  return inner_update(ctx, Msrc, ld_src, G, ldg, Mdst, ld_dst, m, 1.0, -1.0, stream);
+}
+
+static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
+                        int m, double alpha, double sign, void* stream) {
   if (!ctx || m < 0 || (m > 0 && (!Msrc || !G || !Mdst || ld_src < m || ldg < m || ld_dst < m))) return FH_EINVAL;
   if (m == 0) return 0;
   if (m > kWbMax) return FH_ESIZE;  // the caller falls back to its host path
@@ -1373,7 +1700,8 @@ int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const dou
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_woodbury_inner, dim3(1), dim3(256), lds, (hipStream_t)stream, Msrc, ld_src, G, ldg, Mdst, ld_dst, m);
+  hipLaunchKernelGGL(k_woodbury_inner, dim3(1), dim3(256), lds, (hipStream_t)stream, Msrc, ld_src, G, ldg, Mdst, ld_dst, m,
+                     alpha, sign);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -1393,6 +1721,32 @@ static int cov_invert(fh_context* ctx, const fh_cov_state* st, int src, int dst,
   return fh_woodbury_inner(ctx, st->M[src], st->ldm, st->G, st->ldg, st->M[dst], st->ldm, m, stream);
 }
 
+// Forward time shift  X <- (X^-1 + s I)^-1  computed from X's OWN representation (online_update_bfgs.py:166-167, 172-173):
+//   D' = D / (1 + s D),  r' = r / (1 + s D),  M' = M (I + s G M)^-1  with  G = B^T diag(r^2 / (1 + s D)) B,
+// while the inverse representation only moves its diagonal (Dinv += s; its row scale r / D and inner matrix are unchanged).
+// Equal to inverting the shifted inverse representation (what the reference does), but I + s G M has the eigenvalues of
+// I + s X restricted to the factor span - in [1, (sigma / sigma')^2] for the covariance, [1, 2) for the Hessian - whereas
+// the inverse route weights the Gram by 1 / D (1e-4 .. 1e4 with the DCT prior) and loses up to 1e9 of the 1e16.
+static int cov_shift_forward(fh_context* ctx, const fh_cov_state* st, int fwd, int inv, const double* B, int m, double s,
+                             void* stream) {
+  hipStream_t sq = (hipStream_t)stream;
+  const int64_t d = st->d;
+  if (m > 0) {
+    const int ntiles = (m + kGT - 1) / kGT;
+    const int npairs = ntiles * (ntiles + 1) / 2;
+    if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems || st->ldg < m) return FH_ESIZE;
+    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, sq, B, (const double*)st->r[fwd],
+                       (const double*)st->D[fwd], ctx->gpartial, d, m, ntiles, 1, s);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64), dim3(256), 0, sq, (const double*)ctx->gpartial,
+                       kGramRowBlocks, ntiles, m, st->G, st->ldg);
+  }
+  hipLaunchKernelGGL(k_forward_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, sq, st->D[fwd], st->r[fwd], st->D[inv],
+                     s, d);
+  FH_LAUNCH_CHECK();
+  if (m == 0) return 0;
+  return inner_update(ctx, st->M[fwd], st->ldm, st->G, st->ldg, st->M[fwd], st->ldm, m, s, 1.0, stream);
+}
+
 static int cov_fwd(fh_context* ctx, const fh_cov_state* st, const double* in, double* out, int inverse, void* stream) {
   if (st->use_dct) return fh_dct2d(ctx, in, out, 3, inverse, stream);
   if (in != out) return fh_axpby(1.0, in, 0.0, nullptr, out, st->d, stream);
@@ -1403,14 +1757,14 @@ int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x,
                        double shift_h, double sigma_next2, int only_covariance, double* wx, double* ws,
                        double* mean_out, double* score_out, void* stream) {
   if (!ctx || !st || st->m_c > kWbMax || st->m_h > kWbMax) return !ctx || !st ? FH_EINVAL : FH_ESIZE;
-  int rc = cov_invert(ctx, st, 1, 0, st->Bc, st->m_c, shift_c, stream);  // C <- (C^-1 + shift)^-1
+  int rc = cov_shift_forward(ctx, st, 0, 1, st->Bc, st->m_c, shift_c, stream);  // C <- (C^-1 + shift)^-1, C^-1 += shift
   if (rc || only_covariance) return rc;
   if (!x || !score || !wx || !ws || !mean_out || !score_out) return FH_EINVAL;
   if ((rc = cov_fwd(ctx, st, x, wx, 0, stream))) return rc;
   if ((rc = cov_fwd(ctx, st, score, ws, 0, stream))) return rc;
   // t0 = H^-1 score with the OLD Hessian, then H <- (H^-1 + shift)^-1, new score = H t0
   if ((rc = fh_rep_apply(ctx, st->D[3], st->r[3], st->Bh, st->M[3], st->ldm, ws, st->t0, st->d, st->m_h, stream))) return rc;
-  if ((rc = cov_invert(ctx, st, 3, 2, st->Bh, st->m_h, shift_h, stream))) return rc;
+  if ((rc = cov_shift_forward(ctx, st, 2, 3, st->Bh, st->m_h, shift_h, stream))) return rc;
   if ((rc = fh_rep_apply(ctx, st->D[2], st->r[2], st->Bh, st->M[2], st->ldm, st->t0, ws, st->d, st->m_h, stream))) return rc;
   if ((rc = fh_axpby(1.0, wx, sigma_next2, ws, wx, st->d, stream))) return rc;  // mean' = x + s'^2 score'
   if ((rc = cov_fwd(ctx, st, wx, mean_out, 1, stream))) return rc;
@@ -1432,15 +1786,37 @@ int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* m
   if ((rc = fh_space_prep(ctx, de, s2, dx, de, st->scal, st->d, stream))) return rc;  // de <- s2 dm; scal[0] = dx.de
   if ((rc = fh_rep_apply(ctx, st->D[0], st->r[0], st->Bc, st->M[0], st->ldm, dx, cdx, st->d, mc, stream))) return rc;
   if ((rc = fh_dot(ctx, cdx, dx, st->scal, 1, st->d, stream))) return rc;              // scal[1] = dx.(C dx)
+  if (!st->project && mc > 0)  // c = M t of that apply (ctx->coef) is needed after the next dots pass overwrites it
+    hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ctx->coef, st->G, mc);
   double* bc0 = st->project ? nullptr : st->Bc + (int64_t)mc * st->d;
   double* bc1 = st->project ? nullptr : st->Bc + (int64_t)(mc + 1) * st->d;
   if ((rc = fh_space_commit_dev(ctx, de, cdx, st->scal, s2, st->D[0], st->r[0], bc0, bc1, st->D[2], st->r[2],
                                 st->Bh + (int64_t)mh * st->d, st->Bh + (int64_t)(mh + 1) * st->d, st->M[0], st->ldm, mc,
                                 st->M[2], st->ldm, mh, st->project, st->d, stream)))
     return rc;
-  const int mc2 = st->project ? mc : mc + 2, mh2 = mh + 2;
-  if ((rc = cov_invert(ctx, st, 0, 1, st->Bc, mc2, 0.0, stream))) return rc;  // C^-1
-  return cov_invert(ctx, st, 2, 3, st->Bh, mh2, 0.0, stream);                 // H^-1
+  const int mh2 = mh + 2;
+  if (st->project) {
+    // the pair went into the diagonal: C^-1 over the unchanged columns by Woodbury
+    if ((rc = cov_invert(ctx, st, 0, 1, st->Bc, mc, 0.0, stream))) return rc;
+  } else {
+    // C^-1 in closed form (k_bfgs_inverse_commit): cC = M t saved above; s = Wi^T de and Mi s from a dots pass over the
+    // old columns with the inverse representation's row scale; de^T D^-1 de from one more reduction
+    hipStream_t sq = (hipStream_t)stream;
+    if (mc > 0) {
+      fh_batch per;
+      memset(&per, 0, sizeof(per));
+      per.nimg = 1;
+      per.D[0] = st->D[1], per.r[0] = st->r[1], per.B[0] = st->Bc, per.M[0] = st->M[1];
+      if ((rc = rep_apply_launch(ctx, per, st->ldm, de, nullptr, st->d, mc, nullptr, sq))) return rc;
+    }
+    hipLaunchKernelGGL(k_wnorm_partial, dim3(kDotBlocks), dim3(256), 0, sq, (const double*)de, (const double*)st->D[1],
+                       ctx->w2, st->d);
+    hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, sq, (const double*)ctx->w2, kDotBlocks, st->scal + 2);
+    hipLaunchKernelGGL(k_bfgs_inverse_commit, dim3(1), dim3(256), 0, sq, (const double*)st->scal, (const double*)st->G,
+                       (const double*)(ctx->coef + FH_MAX_COLS), (const double*)ctx->coef, st->M[1], st->ldm, mc);
+    FH_LAUNCH_CHECK();
+  }
+  return cov_invert(ctx, st, 2, 3, st->Bh, mh2, 0.0, stream);  // H^-1 (its diagonal was re-derived from C: full Woodbury)
 }
 
 int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k, void* stream) {

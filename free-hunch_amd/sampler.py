@@ -80,6 +80,11 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
     x_next = noise.to(torch.float64) * t_list[0]
     x_all = [x_next.detach()]
     mech = _make_mechanism(other_args, forward_operator, t_list[0], x_next.shape[1:].numel())
+    cov_ctx = getattr(getattr(mech, "covariance_model", None), "ctx", None)
+    if cov_ctx is not None:
+        # one image, one stream: no other grid-synchronising kernel can share the GPU with this image's Free Hunch work,
+        # so the covariance apply may keep the factor base on chip (include/fh_hip.h: fh_context_set_exclusive)
+        cov_ctx.set_exclusive(other_args.get("exclusive_device", True))
     y = cond_images.to(noise.device)
     f64 = lambda v: torch.tensor(v, dtype=torch.float64, device=noise.device)
     for i, (t_cur, t_next) in enumerate(zip(t_list[:-1], t_list[1:])):
@@ -103,6 +108,9 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
             d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * denoised
             x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
     conditional_sampler.last_mechanism = mech
+    if cov_ctx is not None:
+        cov_ctx.status()  # raises if a single-sweep apply gave up waiting for its peers (the result would be invalid)
+        cov_ctx.set_exclusive(False)
     return x_next, x_all, cond_images
 
 
@@ -134,6 +142,10 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
     for b in range(B):
         assert getattr(operators[b], "ctx_slot", 0) == slot_base + b, "every concurrent image needs its own ctx_slot"
         mechs.append(_make_mechanism(o, operators[b], t_list[0], noise.shape[1:].numel()))
+        if hasattr(mechs[-1], "covariance_model"):
+            mechs[-1].covariance_model.ctx.set_exclusive(False)  # the per-image streams run concurrently with each other
+    # the batched CG runs alone on the GPU unless the caller overlaps several lock-step groups (bench.py --groups > 1)
+    exclusive_cg = bool(o.get("exclusive_device", True))
     ys = [m.to(dev) for m in measurements]
     streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
@@ -190,7 +202,8 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             t0 = _tick("update", t0)
             infos = []
             mats = solve_customcuda_batched(operators, ys, [m_det[b:b + 1] for b in range(B)],
-                                            [mm.covariance_model for mm in mechs], o["max_rtol"], t, infos)
+                                            [mm.covariance_model for mm in mechs], o["max_rtol"], t, infos,
+                                            exclusive=exclusive_cg)
             for b in range(B):
                 mechs[b]._rec = dict(infos[b])
         else:
@@ -221,6 +234,9 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * denoised
             x_next = x_hat + h * (0.5 * d_cur + 0.5 * d_prime)
     pool.shutdown()
+    if batched_cg and exclusive_cg:
+        from . import _lib
+        _lib.Context.get(noise.shape[-1], 3 * B, 0, slot=5000 + 64 * slot_base + B).status()
     if prof is not None:
         print("[FH_PHASE_TIMES] seconds per batch:", {k: round(v, 3) for k, v in prof.items()}, flush=True)
     conditional_sampler_batched.last_mechanisms = mechs

@@ -35,7 +35,7 @@ def _wino(w):
 
 
 def _use_wino(N, H, W, K, rows_out):
-    """Measured on MI355X (scratch/bench_wino.py): the fused F(2,3) kernel is 1.23-1.25x the direct kernel when a full
+    """Measured on MI355X (profiles/tools/bench_wino.py): the fused F(2,3) kernel is 1.23-1.25x the direct kernel when a full
     wave of 256-tile workgroups covers the chip (1.11x at K = Cin = 128), ~1.14x with the 128-tile variant at K >= 256;
     smaller grids stay on the direct kernel (or split-K).  Mirrors the variant choice of fh_conv3x3_wino_nhwc."""
     if W % 2 or K % 16 or K < 128:
@@ -57,7 +57,7 @@ def _split3(w):
 
 
 def _use_x6(N, H, W, rows_out):
-    """Measured on MI355X (scratch/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (1.05-1.1x the
+    """Measured on MI355X (profiles/tools/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (1.05-1.1x the
     Winograd one) on the large layers and, with the same deterministic split-K, 1.0-1.2x on the 8 x 8 ... 32 x 32 grids;
     only the thin outputs (<= 64 rows: the 3 / 6 channel image convolutions) stay on the fp32 kernel."""
     return rows_out > 64

@@ -27,6 +27,7 @@ extern "C" {
 #endif
 
 #define FH_EINVAL (-1) /* bad argument (null pointer, size out of range) */
+#define FH_ESYNC (-3)  /* a single-sweep cov-apply gave up waiting for its peer workgroups (see fh_context_set_exclusive) */
 #define FH_ESIZE (-2)  /* size not supported by this build (e.g. m > FH_MAX_COLS) */
 #define FH_MAX_COLS 256
 
@@ -37,6 +38,16 @@ int fh_version(void);
 /* S = image side (<= 256), planes_max = largest planes count that will be passed, m_cap = column capacity */
 int fh_context_create(fh_context** out, int S, int planes_max, int m_cap);
 int fh_context_destroy(fh_context* ctx);
+/* exclusive = 1: the caller guarantees that kernels of this context never run concurrently with another
+ * grid-synchronising kernel on the same GPU (one FH stream per process, e.g. the single-image sampler or the lock-step
+ * batched CG).  The covariance apply (fh_rep_apply[_batched], and inside fh_cg_solve[_batched] / fh_amm / the covariance
+ * updates) then takes the single-sweep kernel that keeps the factor base in registers between the reduction and the
+ * product (B read once instead of twice).  Default 0: two-pass kernels, safe under any concurrency.  Results are bitwise
+ * identical in both modes. */
+int fh_context_set_exclusive(fh_context* ctx, int exclusive);
+/* 0, or FH_ESYNC if a single-sweep apply of this context timed out waiting for its peer workgroups since the last call
+ * (its output was invalid; the context then stays on the two-pass kernels).  Synchronises the stream. */
+int fh_context_status(fh_context* ctx, void* stream);
 
 /* 2-D orthonormal DCT-II (inverse = 0) / DCT-III (inverse = 1) over the last two axes of
  * in[planes][S][S].  Replaces torch_dct.dct_2d / idct_2d(norm='ortho'),
@@ -104,7 +115,15 @@ typedef struct fh_cov_state {
 } fh_cov_state;
 
 /* x, score: image-space d-vectors; wx, ws: d-vectors of scratch; mean_out, score_out: results (image space).
- * shift_c = float32(s'^-2 - s^-2), shift_h = -float32(s'^2 - s^2) (the reference's float32-rounded increments). */
+ * shift_c = float32(s'^-2 - s^-2), shift_h = -float32(s'^2 - s^2) (the reference's float32-rounded increments).
+ * Time update (online_update_bfgs.py:157-192): the reference shifts the diagonal of C^-1 (H^-1) and rebuilds C (H) by
+ * Woodbury from the inverse; here the same matrices are formed from C's (H's) OWN representation,
+ *   D' = D / (1 + s D), r' = r / (1 + s D), M' = M (I + s G M)^-1, G = B^T diag(r^2 / (1 + s D)) B,
+ * and the inverse representation only moves its diagonal - algebraically identical, without the 1 / D weighting of the
+ * Gram matrix that costs up to 1e9 of float64's 1e16 at d = 196608 with the DCT prior.
+ * Space update (:250-312): pair appended to C and H; C^-1 by the closed-form BFGS inverse
+ *   (I - g dx de^T) C^-1 (I - g de dx^T) + g dx dx^T  expressed in the shared base (no inversion);
+ * H^-1 by Woodbury (its diagonal is re-derived from C, :296).  With project_to_diagonal C^-1 is a Woodbury inverse too. */
 int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x, const double* score, double shift_c,
                        double shift_h, double sigma_next2, int only_covariance, double* wx, double* ws,
                        double* mean_out, double* score_out, void* stream);

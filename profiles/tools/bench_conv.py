@@ -1,5 +1,5 @@
 import os, sys, torch, time
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from free_hunch_amd import _lib as L
 lib=L.load(); dev=torch.device('cuda:0')
 shapes=[(1,256,256,128,128,3),(8,256,256,128,128,3),(1,256,256,256,128,3),(1,128,128,128,128,3),(1,64,64,256,256,3),(8,64,64,256,256,3),

@@ -1,5 +1,5 @@
 import os, sys, json, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from bench import roofline_dense_cov_apply
 dev=torch.device('cuda:0')
 for d in (4096, 12288):

@@ -1,5 +1,5 @@
 import os, sys, torch
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from free_hunch_amd import _lib
 dev=torch.device('cuda:0'); S=256; d=3*S*S
 ctx=_lib.Context.get(S,3,128)

@@ -1,5 +1,5 @@
 import os, sys, torch, time, collections
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from bench import build_net
 from free_hunch_amd import unet_hip
 dev=torch.device('cuda:0')

@@ -1,5 +1,5 @@
 import os, sys, torch, time
-ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from bench import build_net
 dev=torch.device('cuda:0')
 arch=sys.argv[1] if len(sys.argv)>1 else "ffhq"; bs=int(sys.argv[2]) if len(sys.argv)>2 else 8

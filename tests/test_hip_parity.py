@@ -417,7 +417,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     fo.conditional_sampler(onet, noise, y, oop, num_steps=int(g[p + "num_steps"]), solver=str(g[p + "solver"]),
                            mechanism_factory=lambda op_, v0, d: Pair(op_, v0, d))
     assert len(rows) == len(g[p + "niter"])
-    tight = 0
+    tight = loose = 0
     for r in rows:
         assert r["ko"] == r["kh"], r
         assert r["bo"] == r["bh"], r
@@ -431,6 +431,14 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
         elif r["no"] == r["nh"] and r["no"] <= 20 and r["sigma"] < 20:
             assert rel < 1e-4, r
             tight += 1
+        elif r["no"] == r["nh"]:
+            # an un-converged iterate of a long solve at high sigma (rtol 0.1 .. 1): equal iteration counts, but the oracle
+            # blurs through the reference's complex64 OTF (6e-8 per frequency) and cond(A C A^T + s^2 I) ~ 1e5 amplifies
+            # that difference: bounded by the solver test's 5e-3 rather than by rounding
+            assert rel < 5e-3, r
+            loose += 1
+    # every call with equal iteration counts carries a value assertion; at least half of all calls must be of that kind
+    assert tight + loose >= len(rows) // 2, (tight, loose, len(rows))
     assert tight >= len(rows) // 3
 
 
