@@ -48,6 +48,7 @@ _SIGS = {
     "fh_context_destroy": ([C.c_void_p], C.c_int),
     "fh_context_set_exclusive": ([C.c_void_p, C.c_int], C.c_int),
     "fh_context_status": ([C.c_void_p, C.c_void_p], C.c_int),
+    "fh_debug_read_stamps": ([C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p], C.c_int),
     "fh_dct2d": ([C.c_void_p, c_dp, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_apply": ([C.c_void_p, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "fh_rep_apply_batched": ([C.c_void_p, C.POINTER(FhBatch), C.c_int, c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
@@ -163,7 +164,7 @@ class Context:
     def set_exclusive(self, flag):
         """Declare that no other grid-synchronising kernel shares the GPU with this context's stream (include/fh_hip.h):
         the covariance apply then reads the factor base once instead of twice."""
-        check(self.lib.fh_context_set_exclusive(self.h, int(bool(flag))), "fh_context_set_exclusive")
+        check(self.lib.fh_context_set_exclusive(self.h, int(flag)), "fh_context_set_exclusive")
 
     def status(self):
         """Raises if a single-sweep covariance apply of this context timed out since the last call."""

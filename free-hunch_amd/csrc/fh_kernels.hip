@@ -208,6 +208,7 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
 // B is read twice; pass 2 walks the rows in the opposite order so that the tail of pass 1 is still
 // in the Infinity Cache / L2 when it is needed again.
 // ------------------------------------------------------------------------------------------------
+typedef double d2v_t __attribute__((ext_vector_type(2)));  // native vector type: usable with the nontemporal builtins
 constexpr int kDotRows = 768;   // rows per workgroup (d = 196608 -> 256 workgroups, one per CU)
 constexpr int kColChunk = 8;    // columns held in registers per wave and sweep
 
@@ -217,6 +218,16 @@ constexpr int kColChunk = 8;    // columns held in registers per wave and sweep
 // base at m = 32 (a pure streaming read of the same bytes reaches 5.6 TB/s).  Each wave writes its sums as block
 // partials; k_rep_coef (one 1024-thread workgroup) adds them in a fixed order and forms c = M t.  (float64 atomics
 // into a shared m-vector were measured 2x SLOWER than this: 8192 same-address adds serialise at the memory side.)
+// NT: non-temporal loads of B.  A base that does not fit the 256 MB Infinity Cache anyway (8 images x 32 columns = 403 MB)
+// streams 1-4 % faster without allocating there; a smaller one (8 x 16 columns = 201 MB) is re-read from the cache by pass 2
+// and by the next CG iteration, and non-temporal loads cost 15-20 % (measured 97 vs 81 us per batched apply at m = 16).
+template <bool NT>
+__device__ __forceinline__ d2v_t ld_base(const double* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p));
+  return *reinterpret_cast<const d2v_t*>(p);
+}
+
+template <bool NT>
 __global__ __launch_bounds__(256) void k_rep_dots(fh_batch per, const double* __restrict__ z,
                                                   double* __restrict__ partial, int64_t d, int m,
                                                   const fh_cg_state* __restrict__ states) {
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void k_rep_dots(fh_batch per, const double* __
       for (int q = 0; q < kColChunk; ++q) {
         const int j = w + 4 * (q0 + q);
         const int jc = j < m ? j : m - 1;
-        const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)jc * d + row[it]);
+        const d2v_t b = ld_base<NT>(B + (int64_t)jc * d + row[it]);
         acc[q] = fma(b.x, rz[it].x, fma(b.y, rz[it].y, acc[q]));
       }
     }
@@ -315,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_rep_coef(fh_batch per, const double* _
 }
 
 // pass 2: out = D.*z + r.*(B c), rows swept in the opposite order of pass 1 (Infinity-Cache reuse).
+template <bool NT>
 __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* __restrict__ coef,
                                                     const double* __restrict__ z, double* __restrict__ out,
                                                     int64_t d, int m, const fh_cg_state* __restrict__ states) {
@@ -337,16 +349,27 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
     double2 ch[8];
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) ch[w8] = make_double2(0.0, 0.0);
-    for (int j0 = 0; j0 < m; j0 += 8) {
+    const int mfull = m & ~7;
+    for (int j0 = 0; j0 < mfull; j0 += 8) {  // eight independent streaming loads per step
+      d2v_t b[8];
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8)
+        b[w8] = ld_base<NT>(B + (int64_t)(j0 + w8) * d + i0);
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) {
-        const int j = j0 + w8;
-        if (j < m) {
-          const double2 b = *reinterpret_cast<const double2*>(B + (int64_t)j * d + i0);
-          const double cj = c[j];
-          ch[w8].x = fma(b.x, cj, ch[w8].x);
-          ch[w8].y = fma(b.y, cj, ch[w8].y);
-        }
+        const double cj = c[j0 + w8];
+        ch[w8].x = fma(b[w8].x, cj, ch[w8].x);
+        ch[w8].y = fma(b[w8].y, cj, ch[w8].y);
+      }
+    }
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) {
+      const int j = mfull + w8;
+      if (j < m) {
+        const d2v_t b = ld_base<NT>(B + (int64_t)j * d + i0);
+        const double cj = c[j];
+        ch[w8].x = fma(b.x, cj, ch[w8].x);
+        ch[w8].y = fma(b.y, cj, ch[w8].y);
       }
     }
     double2 acc = ch[0];
@@ -394,9 +417,15 @@ template <int MC>
 __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per, const double* __restrict__ z,
                                                                     double* __restrict__ out, double* __restrict__ partial,
                                                                     unsigned int* __restrict__ sync, int64_t d, int m,
-                                                                    int ldm, const fh_cg_state* __restrict__ states) {
+                                                                    int ldm, const fh_cg_state* __restrict__ states,
+                                                                    unsigned long long* __restrict__ dbg) {
   const int img = blockIdx.z;
   IMG_GUARD(states, img);
+  // dbg != null (profiling builds of the launcher only): thread 0 records the 100 MHz wall clock at the phase boundaries
+#define FUSED_STAMP(k)                                                                                          \
+  if (dbg != nullptr && threadIdx.x == 0)                                                                       \
+  dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime()
+  FUSED_STAMP(0);
   const double* __restrict__ B = per.B[img];
   const double* __restrict__ r = per.r[img];
   const double* __restrict__ D = per.D[img];
@@ -412,10 +441,13 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
   const int64_t r0 = (int64_t)blockIdx.x * kDotRows + 2 * lane;  // d is a multiple of kDotRows on this path
   constexpr int kIter = kDotRows / 128;
 
-  __shared__ __align__(16) double psum[8][kDotRows];  // per-wave chains of (B c) over the workgroup's rows
-  __shared__ double red[32][33];
+  constexpr int MS = 8 * MC;                          // columns this instantiation can hold
+  __shared__ __align__(16) double psum[8][kDotRows];  // phase 1: r.*z; phase 2a: reduction scratch; 2c: per-wave chains of (B c)
+  __shared__ __align__(16) double dzs[kDotRows], rrs[kDotRows];  // D.*z and r of the workgroup's rows (read before the barrier)
+  __shared__ double Msh[MS][MS + 1];                  // the inner matrix, staged before the barrier as well
   __shared__ double tsh[64], csh[64];
   __shared__ int ok_s;
+  double(*red)[33] = reinterpret_cast<double(*)[33]>(&psum[1][0]);  // [32][33] doubles inside psum (free in phase 2a)
 
   // ---- phase 1: r.*z of the workgroup's rows goes through LDS (every wave needs all of it; holding it in registers next
   // to the slice would spill at the 128-VGPR budget of two workgroups per CU)
@@ -424,7 +456,13 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
     const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
     const double2 zz = *reinterpret_cast<const double2*>(z + i0);
     const double2 rr = *reinterpret_cast<const double2*>(r + i0);
+    const double2 dd = *reinterpret_cast<const double2*>(D + i0);
     *reinterpret_cast<double2*>(rzs + 2 * tid) = make_double2(zz.x * rr.x, zz.y * rr.y);
+    *reinterpret_cast<double2*>(dzs + 2 * tid) = make_double2(dd.x * zz.x, dd.y * zz.y);
+    *reinterpret_cast<double2*>(rrs + 2 * tid) = rr;
+  } else {
+    // the other two waves stage M (everything the latency chain after the barrier would otherwise have to fetch)
+    for (int i = tid - kDotRows / 2; i < m * m; i += 512 - kDotRows / 2) Msh[i / m][i % m] = M[(int64_t)(i / m) * ldm + i % m];
   }
   double2 breg[MC][kIter];
 #pragma unroll
@@ -439,7 +477,7 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
       for (int it = 0; it < kIter; ++it) breg[q][it] = make_double2(0.0, 0.0);
     }
   }
-  __syncthreads();
+  __syncthreads();  // r.*z, D.*z, r and M are in LDS
 #pragma unroll
   for (int q = 0; q < MC; ++q) {
     double acc = 0.0;
@@ -455,8 +493,10 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
     asm volatile("" ::: "memory");  // re-read r.*z from LDS for the next column instead of keeping it live
   }
   // ---- arrive + wait
+  FUSED_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  FUSED_STAMP(2);
   if (tid == 0) {
     __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1, spins = 0;
@@ -472,6 +512,7 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
   }
   __syncthreads();
   if (!ok_s) return;  // uniform: every wave of the workgroup leaves
+  FUSED_STAMP(3);
 
   // ---- phase 2a: t = sum of the block partials, in k_rep_coef's order: row group rg = 0..31 adds the blocks
   // rg, rg + 64, ... into one chain and rg + 32, rg + 96, ... into a second one.  The 16 sc1 loads of a thread are issued
@@ -511,6 +552,7 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
     }
     __syncthreads();
   }
+  FUSED_STAMP(4);
   // every partial this workgroup needs has been read: depart; the last one re-arms the image's counters for the next launch
   if (tid == 0) {
     const unsigned int prev = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -524,7 +566,7 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
     const int rowi = q0 + rg2;
     double sum = 0.0;
     if (rowi < m)
-      for (int l = jj; l < m; l += 32) sum = fma(M[(int64_t)rowi * ldm + l], tsh[l], sum);
+      for (int l = jj; l < m; l += 32) sum = fma(Msh[rowi][l], tsh[l], sum);
     sum += __shfl_xor(sum, 1, 64);
     sum += __shfl_xor(sum, 2, 64);
     sum += __shfl_xor(sum, 4, 64);
@@ -550,6 +592,7 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
     }
   }
   __syncthreads();
+  FUSED_STAMP(5);
   // ---- phase 2d: out = D.*z + r.*(chains added in the order w = 0 .. 7)
   if (tid < kDotRows / 2) {
     double2 acc = *reinterpret_cast<const double2*>(&psum[0][2 * tid]);
@@ -559,11 +602,12 @@ __global__ __launch_bounds__(512, MC <= 4 ? 4 : 2) void k_rep_fused(fh_batch per
       acc.x += p.x, acc.y += p.y;
     }
     const int64_t i0 = (int64_t)blockIdx.x * kDotRows + 2 * tid;
-    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
-    const double2 dd = *reinterpret_cast<const double2*>(D + i0);
-    const double2 rr = *reinterpret_cast<const double2*>(r + i0);
-    *reinterpret_cast<double2*>(out + i0) = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
+    const double2 dz = *reinterpret_cast<const double2*>(dzs + 2 * tid);
+    const double2 rr = *reinterpret_cast<const double2*>(rrs + 2 * tid);
+    *reinterpret_cast<double2*>(out + i0) = make_double2(fma(rr.x, acc.x, dz.x), fma(rr.y, acc.y, dz.y));
   }
+  FUSED_STAMP(6);
+#undef FUSED_STAMP
 }
 
 static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const double* z, double* out, int64_t d,
@@ -576,24 +620,39 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
   // TB/s): same order 2.75, reverse order 2.97; splitting the batch into cache-sized groups of 4 (each group both
   // passes back to back) 2.80 - the extra dependent launches cost more than the additional hits return.
   const unsigned Z = (unsigned)per.nimg;
+  // Single-sweep kernel: one image per launch on an exclusive context.  (Several images per launch are correct - the test
+  // suite runs them with fh_context_set_exclusive(ctx, 2) - but slower than the two-pass kernels: the hand-off of one image goes through
+  // the same per-CU memory queues as the next image's streaming loads and stretches from 13 us to 19 us, see
+  // profiles/r02_cov_apply_single_sweep.md.)
   if (out != nullptr && m > 0 && m <= 64 && ctx->exclusive && !ctx->fused_disabled && d % kDotRows == 0 && nb <= ctx->num_cus &&
-      nb <= 256) {
+      nb <= 256 && (per.nimg == 1 || ctx->exclusive >= 2)) {
+    unsigned long long* dbg = getenv("FH_FUSED_DEBUG") ? (unsigned long long*)ctx->gpartial : nullptr;  // profiling only
     if (m <= 32)
       hipLaunchKernelGGL((k_rep_fused<4>), dim3(nb, 1, Z), dim3(512), 0, st, per, z, out, ctx->partial, ctx->sync, d, m, ldm,
-                         states);
+                         states, dbg);
     else
       hipLaunchKernelGGL((k_rep_fused<8>), dim3(nb, 1, Z), dim3(512), 0, st, per, z, out, ctx->partial, ctx->sync, d, m, ldm,
-                         states);
+                         states, dbg);
     FH_LAUNCH_CHECK();
     return 0;
   }
+  const bool nt = (int64_t)per.nimg * m * d * (int64_t)sizeof(double) > ((int64_t)220 << 20);  // beyond the Infinity Cache
   if (m > 0) {
-    hipLaunchKernelGGL(k_rep_dots, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
+    if (nt)
+      hipLaunchKernelGGL(k_rep_dots<true>, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
+    else
+      hipLaunchKernelGGL(k_rep_dots<false>, dim3(nb, 1, Z), dim3(256), 0, st, per, z, ctx->partial, d, m, states);
     hipLaunchKernelGGL(k_rep_coef, dim3(1, 1, Z), dim3(1024), 0, st, per, (const double*)ctx->partial, nb, ldm, m,
                        ctx->coef, states);
   }
-  if (out != nullptr)  // out == null: only t = B^T (r.*z) and c = M t are wanted (left in ctx->coef[FH_MAX_COLS..] / [0..])
-    hipLaunchKernelGGL(k_rep_apply2, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m, states);
+  if (out != nullptr) {  // out == null: only t = B^T (r.*z) and c = M t are wanted (left in ctx->coef[FH_MAX_COLS..] / [0..])
+    if (nt)
+      hipLaunchKernelGGL(k_rep_apply2<true>, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m,
+                         states);
+    else
+      hipLaunchKernelGGL(k_rep_apply2<false>, dim3(nb, 1, Z), dim3(256), 0, st, per, (const double*)ctx->coef, z, out, d, m,
+                         states);
+  }
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -1569,7 +1628,14 @@ int fh_context_destroy(fh_context* c) {
 
 int fh_context_set_exclusive(fh_context* ctx, int exclusive) {
   if (!ctx) return FH_EINVAL;
-  ctx->exclusive = exclusive ? 1 : 0;
+  ctx->exclusive = exclusive < 0 ? 0 : (exclusive > 2 ? 2 : exclusive);
+  return 0;
+}
+
+int fh_debug_read_stamps(fh_context* ctx, unsigned long long* out_host, int count, void* stream) {
+  if (!ctx || !out_host || count < 1 || (int64_t)count > ctx->gpartial_elems) return FH_EINVAL;
+  FH_CHECK(hipMemcpyAsync(out_host, ctx->gpartial, sizeof(unsigned long long) * count, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 

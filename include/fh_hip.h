@@ -42,12 +42,16 @@ int fh_context_destroy(fh_context* ctx);
  * grid-synchronising kernel on the same GPU (one FH stream per process, e.g. the single-image sampler or the lock-step
  * batched CG).  The covariance apply (fh_rep_apply[_batched], and inside fh_cg_solve[_batched] / fh_amm / the covariance
  * updates) then takes the single-sweep kernel that keeps the factor base in registers between the reduction and the
- * product (B read once instead of twice).  Default 0: two-pass kernels, safe under any concurrency.  Results are bitwise
- * identical in both modes. */
+ * product (B read once instead of twice) for single-image launches; exclusive = 2 extends that to batched launches
+ * (correct, but measured slower than the two-pass kernels - kept for the tests and for profiling).  Default 0: two-pass
+ * kernels, safe under any concurrency.  Results are bitwise identical in all modes. */
 int fh_context_set_exclusive(fh_context* ctx, int exclusive);
 /* 0, or FH_ESYNC if a single-sweep apply of this context timed out waiting for its peer workgroups since the last call
  * (its output was invalid; the context then stays on the two-pass kernels).  Synchronises the stream. */
 int fh_context_status(fh_context* ctx, void* stream);
+/* profiling aid: with FH_FUSED_DEBUG set in the environment the single-sweep apply records the 100 MHz wall clock at its
+ * phase boundaries (8 words per workgroup, in the Gram scratch); this copies `count` words to the host. */
+int fh_debug_read_stamps(fh_context* ctx, unsigned long long* out_host, int count, void* stream);
 
 /* 2-D orthonormal DCT-II (inverse = 0) / DCT-III (inverse = 1) over the last two axes of
  * in[planes][S][S].  Replaces torch_dct.dct_2d / idct_2d(norm='ortho'),
