@@ -48,11 +48,11 @@ def fh_kwargs(data_dir, solver):
                 do_space_updates=True, solver_type="customcuda")
 
 
-def build_net(arch, device, backend):
+def build_net(arch, device, backend, dtype="fp32"):
     from free_hunch_amd import unet as hu
     from free_hunch_amd.precond import iDDPMLinearPrecond
     cfg = {"ffhq": hu.FFHQ256, "imagenet": hu.IMAGENET256}[arch]
-    model = hu.UNetModel(cfg, backend=backend)
+    model = hu.UNetModel(cfg, backend=backend, dtype=dtype)
     model.load_state_dict(hu.seeded_state(cfg, 0))
     model = model.to(device).eval()
     return iDDPMLinearPrecond(model, cfg.image_size, 3).to(device), cfg
@@ -404,6 +404,8 @@ def main():
     ap.add_argument("--num-steps", type=int, default=30)
     ap.add_argument("--solver", default="heun")
     ap.add_argument("--unet-backend", default=os.environ.get("FH_UNET_BACKEND", "hip"))
+    ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: reduced-precision torso (non-parity speed mode, reported separately from the fp32 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=4)
     a = ap.parse_args()
@@ -439,7 +441,7 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     data_dir = os.path.join(ROOT, "free-hunch_amd", "data")
-    net, cfg = build_net(a.arch, device, a.unet_backend)
+    net, cfg = build_net(a.arch, device, a.unet_backend, a.unet_dtype)
     images = smooth_images(a.batch, 256, 1234 + rank)
 
     def step(i):
@@ -456,7 +458,11 @@ def main():
             "metric": f"images/sec (256x256, num_steps={a.num_steps}, FH-{a.solver.capitalize()})",
             "value": round(total_images / elapsed, 5), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": ("f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy)" if os.environ.get("FH_CONV_MODE", "x6") == "x6" else "f32 UNet (fp32 MFMA)") + " + f64 covariance/CG", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("bf16-compute UNet convolutions (NON-PARITY mode), f32 elsewhere" if a.unet_dtype == "bf16" else
+                      "f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy)"
+                      if os.environ.get("FH_CONV_MODE", "x6") == "x6" else "f32 UNet (fp32 MFMA)") + " + f64 covariance/CG",
+            "data": "synthetic",
             "config": {"workload": f"{a.arch.upper()}-256 arch, {a.operator}, FH low-rank covariance (dct_diagonal), "
                                    f"num_steps={a.num_steps} {a.solver}, batch={a.batch} per GPU",
                        "images_per_step": a.batch * world, "lockstep_groups_per_gpu": a.groups,

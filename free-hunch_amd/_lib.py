@@ -19,7 +19,8 @@ class FhProblem(C.Structure):
                 ("d", C.c_int64), ("sigma_y2", C.c_double),
                 ("tap_dy", c_dp), ("tap_dx", c_dp), ("tap_w", c_dp), ("mask", c_dp),
                 ("D", c_dp), ("r", c_dp), ("B", c_dp), ("M", c_dp),
-                ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("tap2_dy", c_dp), ("tap2_dx", c_dp), ("tap2_w", c_dp)]
+                ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("tap2_dy", c_dp), ("tap2_dx", c_dp), ("tap2_w", c_dp),
+                ("fold_fwd_w", c_dp), ("fold_fwd_h", c_dp), ("fold_inv_w", c_dp), ("fold_inv_h", c_dp)]
 
 
 FH_MAX_BATCH = 16
@@ -76,6 +77,7 @@ _SIGS = {
     "fh_conv2d_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_x6_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
+    "fh_unet_set_precision": ([C.c_int], C.c_int),
     "fh_groupnorm_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_conv2d_x6_norm_supported": ([C.c_int] * 5, C.c_int),
     "fh_conv2d_x6_norm_nhwc": ([c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),

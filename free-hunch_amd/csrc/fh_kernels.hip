@@ -38,7 +38,8 @@ template <bool BT, int TM, int TN = TM>  // TM x TN MFMA tiles (16x16) per wave:
 __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, const double* __restrict__ B,
                                                   double* __restrict__ C, int M, int N, int K, int lda, int ldb,
                                                   int ldc, int64_t sA, int64_t sB, int64_t sC,
-                                                  const fh_cg_state* __restrict__ states, int rows_per_plane) {
+                                                  const fh_cg_state* __restrict__ states, int rows_per_plane,
+                                                  const double* __restrict__ add, double add_scale) {
   constexpr int BM = 32 * TM, BN = 32 * TN, BK = 32, LD = BK + 2;
   IMG_GUARD(states, ((int)blockIdx.z + (int)(blockIdx.y * BM) / rows_per_plane) / 3);
   __shared__ __align__(16) double As[2][BM][LD];
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   A += sA * blockIdx.z;
   B += sB * blockIdx.z;
   C += sC * blockIdx.z;
+  if (add != nullptr) add += sC * blockIdx.z;  // epilogue C = acc + add_scale * add, same layout as C
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 16 * TM, wn = (wave & 1) * 16 * TN;
@@ -150,17 +152,31 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gm = m0 + wm + 16 * i + lk + 4 * r;
-        if (gm < M) C[(int64_t)gm * ldc + gn] = acc[i][j][r];
+        if (gm < M) {
+          const int64_t o = (int64_t)gm * ldc + gn;
+          C[o] = add != nullptr ? fma(add_scale, add[o], acc[i][j][r]) : acc[i][j][r];
+        }
       }
     }
   }
 }
 
+// Two dense S x S passes over `planes` images: T = X b_w^T (along W), out = b_h T (along H) [+ add_scale * add].
+// b_w = b_h = the DCT basis (or its transpose) gives the 2-D DCT-II / DCT-III; a separable blur folded into the bases
+// (fh_problem.fold_*) makes the same two passes compute dct2(A^T x) or A(idct2(x)).
+static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, int planes, const double* b_w, const double* b_h,
+                              const double* add, double add_scale, const fh_cg_state* states, hipStream_t st);
+
 static int dct2d_launch(fh_context* ctx, const double* in, double* out, int planes, int inverse,
                         const fh_cg_state* states, hipStream_t st) {
+  const double* b1 = inverse ? ctx->basis_t : ctx->basis;
+  return dct2d_launch_bases(ctx, in, out, planes, b1, b1, nullptr, 0.0, states, st);
+}
+
+static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, int planes, const double* b1, const double* b2,
+                              const double* add, double add_scale, const fh_cg_state* states, hipStream_t st) {
   const int S = ctx->S;
   if (planes > ctx->planes_max) return FH_ESIZE;
-  const double* b1 = inverse ? ctx->basis_t : ctx->basis;
   // Tile choice by workgroup count (256 CUs, the GEMMs are MFMA-bound: what matters is an even number of tile-units per
   // CU).  64x64 tiles halve the LDS/global traffic per flop but S = 256, 24 planes gives 384 of them = 1.5 per CU
   // (half the CUs carry two: 24 us); 64x32 tiles give 768 = exactly 3 half-size units per CU.
@@ -172,29 +188,29 @@ static int dct2d_launch(fh_context* ctx, const double* in, double* out, int plan
   if (tile == 1) {
     dim3 grid((S + 63) / 64, (planes * S + 63) / 64, 1);
     hipLaunchKernelGGL((k_gemm_f64<true, 2, 2>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S, (const double*)nullptr, 0.0);
   } else if (tile == 2) {
     dim3 grid((S + 31) / 32, (planes * S + 63) / 64, 1);
     hipLaunchKernelGGL((k_gemm_f64<true, 2, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S, (const double*)nullptr, 0.0);
   } else {
     dim3 grid((S + 31) / 32, (planes * S + 31) / 32, 1);
     hipLaunchKernelGGL((k_gemm_f64<true, 1, 1>), grid, dim3(256), 0, st, in, b1, ctx->tmp_img, planes * S, S, S, S, S, S,
-                       (int64_t)0, (int64_t)0, (int64_t)0, states, S);
+                       (int64_t)0, (int64_t)0, (int64_t)0, states, S, (const double*)nullptr, 0.0);
   }
   // pass 2 (along H), per plane: Y[k][w] = sum_n b1[k][n] * T[n][w]
   if (tile == 1) {
     dim3 grid((S + 63) / 64, (S + 63) / 64, planes);
-    hipLaunchKernelGGL((k_gemm_f64<false, 2, 2>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    hipLaunchKernelGGL((k_gemm_f64<false, 2, 2>), grid, dim3(256), 0, st, b2, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30, add, add_scale);
   } else if (tile == 2) {
     dim3 grid((S + 31) / 32, (S + 63) / 64, planes);
-    hipLaunchKernelGGL((k_gemm_f64<false, 2, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    hipLaunchKernelGGL((k_gemm_f64<false, 2, 1>), grid, dim3(256), 0, st, b2, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30, add, add_scale);
   } else {
     dim3 grid((S + 31) / 32, (S + 31) / 32, planes);
-    hipLaunchKernelGGL((k_gemm_f64<false, 1, 1>), grid, dim3(256), 0, st, b1, (const double*)ctx->tmp_img, out, S, S, S, S,
-                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30);
+    hipLaunchKernelGGL((k_gemm_f64<false, 1, 1>), grid, dim3(256), 0, st, b2, (const double*)ctx->tmp_img, out, S, S, S, S,
+                       S, S, (int64_t)0, (int64_t)S * S, (int64_t)S * S, states, 1 << 30, add, add_scale);
   }
   FH_LAUNCH_CHECK();
   return 0;
@@ -1352,6 +1368,16 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per,
   const dim3 egrid(512, 1, (unsigned)nimg);
   const bool sep = p->ntaps2 > 0;  // separable PSF: two 1-D passes (blur only, stride 1)
   if (sep && p->stride != 1) return FH_EINVAL;
+  if (p->op == 1 && p->use_dct && p->fold_fwd_w != nullptr) {
+    // separable blur folded into the DCT bases: out = sigma_y^2 u + A idct2( C dct2(A^T u) ) in 4 dense passes + the
+    // apply, instead of 4 blur passes + 4 DCT passes + the apply + an axpy epilogue
+    if (!p->fold_fwd_h || !p->fold_inv_w || !p->fold_inv_h) return FH_EINVAL;
+    rc = dct2d_launch_bases(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, nullptr, 0.0, states, st);
+    if (rc) return rc;
+    rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
+    if (rc) return rc;
+    return dct2d_launch_bases(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, u, p->sigma_y2, states, st);
+  }
   // w0 = A^T u
   if (p->op == 0) {
     hipLaunchKernelGGL(k_mask, egrid, dim3(256), 0, st, per, u, (const double*)nullptr, 0.0, w0, d, states);

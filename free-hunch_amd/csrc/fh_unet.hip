@@ -212,15 +212,17 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r;
 }
 
-template <int MI, int NI, int WM, int WN, int MINW>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
+// NP = 3: the exact split above (six products).  NP = 1: plain bf16 compute - operands rounded to bf16 (plane 0 = rn(x)),
+// one product, fp32 accumulation: the reduced-precision mode of the UNet (fh_unet_set_precision; NOT an fp32-parity mode).
+template <int MI, int NI, int WM, int WN, int MINW, int NP = 3>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
 __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
   constexpr int T = 64 * WM * WN;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int IA = BM * 8 / T;      // float4 items per thread per chunk (A tile = BM rows x 8 float4)
-  constexpr int IB = 3 * BN * 4 / T;  // 16-byte items per thread per chunk (B tile = 3 planes x BN rows x 4 parts)
-  static_assert(BM * 8 % T == 0 && 3 * BN * 4 % T == 0, "tile / thread-count mismatch");
-  __shared__ __align__(16) __bf16 As[3][BM][kXLd];
-  __shared__ __align__(16) __bf16 Bs[3][BN][kXLd];
+  constexpr int IB = (NP * BN * 4 + T - 1) / T;  // 16-byte items per thread per chunk (B tile = NP planes x BN rows x 4 parts)
+  static_assert(BM * 8 % T == 0, "tile / thread-count mismatch");
+  __shared__ __align__(16) __bf16 As[NP][BM][kXLd];
+  __shared__ __align__(16) __bf16 Bs[NP][BN][kXLd];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
@@ -263,9 +265,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 #pragma unroll
   for (int e = 0; e < IB; ++e) {
     const int idx = e * T + tid;
-    b_pl[e] = idx / (BN * 4);
+    b_pl[e] = idx < NP * BN * 4 ? idx / (BN * 4) : -1;
     b_row[e] = (idx % (BN * 4)) >> 2;
-    b_ok[e] = n0 + b_row[e] < a.Cout;
+    b_ok[e] = b_pl[e] >= 0 && n0 + b_row[e] < a.Cout;
   }
 
   float4 ra_reg[IA];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
       bf16x8_t z;
 #pragma unroll
       for (int q = 0; q < 8; ++q) z[q] = (__bf16)0.f;
-      const __bf16* src = wbase + b_pl[e] * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
+      const __bf16* src = wbase + (b_ok[e] ? b_pl[e] : 0) * wplane + (int64_t)(b_ok[e] ? n0 + b_row[e] : 0) * kBK + b_part;
       rb_reg[e] = b_ok[e] ? *reinterpret_cast<const bf16x8_t*>(src) : z;
     }
   };
@@ -305,11 +307,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
-      *reinterpret_cast<bf16x4_t*>(&As[1][a_row[e]][a_c4]) = m4;
-      *reinterpret_cast<bf16x4_t*>(&As[2][a_row[e]][a_c4]) = l4;
+      if (NP == 3) {
+        *reinterpret_cast<bf16x4_t*>(&As[NP - 2][a_row[e]][a_c4]) = m4;
+        *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < IB; ++e) *reinterpret_cast<bf16x8_t*>(&Bs[b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
+    for (int e = 0; e < IB; ++e)
+      if (b_pl[e] >= 0) *reinterpret_cast<bf16x8_t*>(&Bs[b_pl[e]][b_row[e]][b_part]) = rb_reg[e];
   };
 
   float16_t acc[MI][NI];
@@ -324,9 +329,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 #pragma unroll
   for (int ks = 0; ks < kBK / 16; ++ks) {
     const int ko = ks * 16 + 8 * lh;
-    bf16x8_t af[3][MI], bfr[3][NI];
+    bf16x8_t af[NP][MI], bfr[NP][NI];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][wm + i * 32 + lr][ko]);
 #pragma unroll
@@ -337,11 +342,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float16_t t = acc[i][j];
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], t, 0, 0, 0);  // l h'
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], t, 0, 0, 0);  // h l'
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], t, 0, 0, 0);  // m m'
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], t, 0, 0, 0);  // m h'
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], t, 0, 0, 0);  // h m'
+        if (NP == 3) {
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bfr[0][j], t, 0, 0, 0);       // l h'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 1][j], t, 0, 0, 0);       // h l'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[NP - 2][j], t, 0, 0, 0);  // m m'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[0][j], t, 0, 0, 0);       // m h'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 2][j], t, 0, 0, 0);       // h m'
+        }
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);  // h h'
         acc[i][j] = t;
       }
@@ -399,16 +406,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // pulls 1.33 B per pixel (fp32, every third tap) but 6 B per output channel (three bf16 planes, every tap): arithmetic
 // intensity 2 BM BN / (1.33 BM + 6 BN) = 35 flop/B at 128 x 128 (-> ~190 TFLOP/s fp32-equivalent, as measured) and 59 at
 // 256 x 128, past the 50 flop/B where the MFMAs at the held clock become the limit.
-template <int SEGW, bool NORM = false, int BM = 128>  // SEGW: pixels per row segment of the tile (W, capped at BM)
+template <int SEGW, bool NORM = false, int BM = 128, int NP = 3>  // SEGW: pixels per row segment of the tile (W, capped at BM)
 __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   constexpr int MI = 2, NI = 1, WN = 4, T = 4 * BM;
   constexpr int NSEG = BM / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
   constexpr int BN = 128, AR = NSEG * SP;
   constexpr int IA = (AR * 8 + T - 1) / T;  // float4 items per thread for the activation tile (1040 items)
-  constexpr int IB = (3 * BN * 4 + T - 1) / T;  // 16-byte items per thread for the weight tile (1536 items)
-  __shared__ __align__(16) __bf16 As[3][AR][kXLd];
+  constexpr int IB = (NP * BN * 4 + T - 1) / T;  // 16-byte items per thread for the weight tile (1536 items at NP = 3)
+  __shared__ __align__(16) __bf16 As[NP][AR][kXLd];
   constexpr int NB = 1;  // (a second weight buffer in the 256-pixel variant, one barrier per tap, was measured: no gain)
-  __shared__ __align__(16) __bf16 Bs[NB][3][BN][kXLd];
+  __shared__ __align__(16) __bf16 Bs[NB][NP][BN][kXLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
   const int lr = lane & 31, lh = lane >> 5;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
   for (int e = 0; e < IB; ++e) {
     const int idx = e * T + tid;
-    b_pl[e] = idx < 3 * BN * 4 ? idx / (BN * 4) : -1;
+    b_pl[e] = idx < NP * BN * 4 ? idx / (BN * 4) : -1;
     b_row[e] = (idx % (BN * 4)) >> 2;
     b_ok[e] = b_pl[e] >= 0 && n0 + b_row[e] < a.Cout;
   }
@@ -498,8 +505,10 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
-      *reinterpret_cast<bf16x4_t*>(&As[1][a_row[e]][a_c4]) = m4;
-      *reinterpret_cast<bf16x4_t*>(&As[2][a_row[e]][a_c4]) = l4;
+      if (NP == 3) {
+        *reinterpret_cast<bf16x4_t*>(&As[NP - 2][a_row[e]][a_c4]) = m4;
+        *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
+      }
     }
   };
   auto store_b = [&](int buf) {
@@ -521,9 +530,9 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
       const int ko = ks * 16 + 8 * lh;
-      bf16x8_t af[3][MI], bfr[3][NI];
+      bf16x8_t af[NP][MI], bfr[NP][NI];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][arow[i] + kx][ko]);
 #pragma unroll
@@ -534,11 +543,13 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           float16_t t = acc[i][j];
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], t, 0, 0, 0);
+          if (NP == 3) {
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bfr[0][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 1][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[NP - 2][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[0][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 2][j], t, 0, 0, 0);
+          }
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);
           acc[i][j] = t;
         }
@@ -1242,6 +1253,23 @@ inline unsigned grid_for(int64_t work_items, int per_block = 256, int cap = 4096
 // ================================================================================================
 extern "C" {
 
+// Precision of the bf16-MFMA convolution kernels: 3 = exact 3-way split (fp32 accuracy, default), 1 = plain bf16 compute
+// (operands rounded to bf16, one product, fp32 accumulation) - the reduced-precision UNet mode, the counterpart of the
+// reference's use_fp16 torso (training/openai_fp16_util.py:15-32).  Process-wide: set before a forward / VJP.
+static int g_conv_np = 3;
+#define X6_DISPATCH(K1, K3, ...)                     \
+  do {                                               \
+    if (g_conv_np == 1)                              \
+      hipLaunchKernelGGL(K1, __VA_ARGS__);           \
+    else                                             \
+      hipLaunchKernelGGL(K3, __VA_ARGS__);           \
+  } while (0)
+
+int fh_unet_set_precision(int bf16_compute) {
+  g_conv_np = bf16_compute ? 1 : 3;
+  return 0;
+}
+
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   // K-split factor for layers whose output grid cannot fill the chip (8x8 ... 32x32 at small batch)
   const int64_t M = (int64_t)N * Ho * Wo;
@@ -1310,26 +1338,26 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
     const bool big = r3 && !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
     if (big && W % 256 == 0)
-      hipLaunchKernelGGL((k_conv_x6r<256, false, 256>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
-      hipLaunchKernelGGL((k_conv_x6r<128, false, 256>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 64 && H % 4 == 0)
-      hipLaunchKernelGGL((k_conv_x6r<64, false, 256>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (r3 && W % 128 == 0)
-      hipLaunchKernelGGL(k_conv_x6r<128>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 64 && H % 2 == 0)
-      hipLaunchKernelGGL(k_conv_x6r<64>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 32 && H % 4 == 0)
-      hipLaunchKernelGGL(k_conv_x6r<32>, dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
   } else if (ksplit > 1 && Cout > 64 && b128 * ksplit >= 256 && !getenv("FH_X6_NOBIGSPLIT")) {
     // small grids: 128 x 128 tiles (21 flop per byte pulled from L2 instead of 12.8) once split-K still fills the chip
-    hipLaunchKernelGGL((k_conv_x6<2, 1, 2, 4, 4>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
-    hipLaunchKernelGGL((k_conv_x6<1, 2, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((k_conv_x6<1, 1, 2, 2, 2>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
   }
   if (ksplit > 1) {
     const int64_t total = M * Cout;
@@ -1390,17 +1418,17 @@ int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, cons
   const bool big = !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
   if (big && W % 256 == 0)
-    hipLaunchKernelGGL((k_conv_x6r<256, true, 256>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
-    hipLaunchKernelGGL((k_conv_x6r<128, true, 256>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 64 && H % 4 == 0)
-    hipLaunchKernelGGL((k_conv_x6r<64, true, 256>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (W % 128 == 0)
-    hipLaunchKernelGGL((k_conv_x6r<128, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 3>), grid, dim3(512), 0, st, a);
   else if (W == 64)
-    hipLaunchKernelGGL((k_conv_x6r<64, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 3>), grid, dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((k_conv_x6r<32, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 3>), grid, dim3(512), 0, st, a);
   FH_LAUNCH_CHECK();
   return 0;
 }

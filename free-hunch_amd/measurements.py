@@ -78,6 +78,41 @@ class Taps(_TapList):
                 self.sep = (_TapList(col[:, None], device), _TapList(row[None, :], device))
 
 
+def dct_basis_longdouble(S):
+    """Orthonormal DCT-II matrix C[k][n] = s_k cos(pi (2n + 1) k / 2S) in extended precision (the same formula the
+    context's device basis is built from, csrc/fh_kernels.hip: fh_context_create)."""
+    ld = np.longdouble
+    k = np.arange(S, dtype=ld)[:, None]
+    n = np.arange(S, dtype=ld)[None, :]
+    C = np.cos(np.arccos(ld(-1)) * (2 * n + 1) * k / (2 * ld(S)))  # arccos(-1) = pi in extended precision
+    C *= np.sqrt(ld(2) / ld(S))
+    C[0] *= np.sqrt(ld(0.5))
+    return C
+
+
+def folded_dct_blur_bases(col_dy, col_w, row_dx, row_w, S):
+    """The two 1-D passes of a separable circular blur folded into the 2-D DCT that follows / precedes them inside the CG
+    operator A C A^T (C lives in the DCT basis):  with the blur A(X) = F_col X F_row^T,
+        dct2(A^T u)  = P_col u P_row^T,        A(idct2(v)) = P_col^T v P_row,        P = C_dct F^T,
+    so the four image passes of the two blurs disappear into the (dense) DCT passes.  F is circulant,
+    F[i][i'] = sum_t w_t [i' = (i - d_t) mod S], hence P[k][n] = sum_t w_t C[k][(n - d_t) mod S] - formed in extended
+    precision and rounded once.  Returns float64 (P_row, P_col, P_row^T, P_col^T), C-contiguous [S][S]."""
+    C = dct_basis_longdouble(S)
+
+    def fold(offsets, weights):
+        P = np.zeros((S, S), dtype=np.longdouble)
+        for d, w in zip(offsets, weights):
+            P += np.longdouble(w) * np.roll(C, int(d), axis=1)
+        return P
+
+    P_row, P_col = fold(row_dx, row_w), fold(col_dy, col_w)
+    f = lambda M: np.ascontiguousarray(M.astype(np.float64))
+    return f(P_row), f(P_col), f(P_row.T), f(P_col.T)
+
+
+_FOLD_CACHE = {}
+
+
 class LinearOperator:
     device = None
 
@@ -102,6 +137,22 @@ class LinearOperator:
         else:
             self._ctx().conv(x64, out, self.taps, planes, stride, adjoint)
         return out
+
+    def folded_bases(self):
+        """Device copies of `folded_dct_blur_bases` for this operator's separable PSF (None when the PSF is not rank-1 or
+        the operator decimates); built once per (PSF, size, device) and shared by all operator instances."""
+        sep = getattr(getattr(self, "taps", None), "sep", None)
+        if sep is None or self.name == "super_resolution" or os.environ.get("FH_NO_FOLD") == "1":
+            return None
+        S = self.in_shape[-1]
+        col, row = sep
+        key = (S, str(self.device), col.dy.cpu().numpy().tobytes(), col.w.cpu().numpy().tobytes(),
+               row.dx.cpu().numpy().tobytes(), row.w.cpu().numpy().tobytes())
+        if key not in _FOLD_CACHE:
+            mats = folded_dct_blur_bases(col.dy.cpu().numpy(), col.w.cpu().numpy(), row.dx.cpu().numpy(),
+                                         row.w.cpu().numpy(), S)
+            _FOLD_CACHE[key] = tuple(torch.from_numpy(m).to(self.device) for m in mats)
+        return _FOLD_CACHE[key]
 
     def _noise(self, y, noiseless):
         if not noiseless:

@@ -243,9 +243,10 @@ class _TorchOps:
 class UNetModel(torch.nn.Module):
     """forward(x [N,3,H,W] float32, timesteps [N]) -> [N, out_channels, H, W]; state-dict keys = the reference's."""
 
-    def __init__(self, cfg: UNetConfig, backend="hip"):
+    def __init__(self, cfg: UNetConfig, backend="hip", dtype="fp32"):
         super().__init__()
         self.cfg, self.backend = cfg, backend
+        self.set_dtype(dtype)
         self.steps, self.ch0 = _plan(cfg)
         self._names = {}
         for k, shp in parameter_shapes(cfg).items():
@@ -256,6 +257,25 @@ class UNetModel(torch.nn.Module):
         self.sigma_min, self.sigma_max = 0.0, 1e20
         self._ops = None
         self._emb = {}
+
+    def set_dtype(self, dtype):
+        """"fp32" (default): every convolution has fp32 accuracy (exact 3-way bf16 split on the matrix cores).
+        "bf16": reduced-precision torso - convolution operands rounded to bf16, fp32 accumulation, everything else
+        (GroupNorm, attention, residuals, storage) stays fp32.  This is the counterpart of the reference's `use_fp16` torso
+        (training/openai_fp16_util.py:15-32); "fp16" is accepted as an alias: gfx950 runs bf16 and fp16 MFMAs at the same
+        rate and bf16 keeps the fp32 exponent range.  Outside the fp32 parity bar - reported as a separate mode."""
+        if dtype == "fp16":
+            import warnings
+            warnings.warn("unet dtype fp16 -> bf16 compute (same MFMA rate on gfx950, fp32 exponent range)")
+            dtype = "bf16"
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(f"unet dtype must be fp32, bf16 or fp16, got {dtype}")
+        if dtype != "fp32" and self.backend != "hip":
+            raise NotImplementedError("the reduced-precision torso exists on the hip backend only")
+        self.dtype_mode = dtype
+        if getattr(self, "_ops", None) is not None and hasattr(self._ops, "bf16"):
+            self._ops.bf16 = dtype == "bf16"
+        return self
 
     # the reference's key names in and out ------------------------------------------------------------
     def state_dict(self, *a, **k):
@@ -286,6 +306,7 @@ class UNetModel(torch.nn.Module):
             elif self.backend == "hip":
                 from .unet_hip import HipOps
                 self._ops = HipOps(self.cfg, self._params())
+                self._ops.bf16 = self.dtype_mode == "bf16"
             else:
                 raise ValueError(f"unknown backend {self.backend}")
         return self._ops
@@ -314,22 +335,23 @@ class UNetModel(torch.nn.Module):
 def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,
                  use_checkpoint=False, attention_resolutions="16", num_heads=1, num_head_channels=-1,
                  num_heads_upsample=-1, use_scale_shift_norm=False, dropout=0, resblock_updown=False,
-                 use_fp16=False, use_new_attention_order=False, backend="hip"):
+                 use_fp16=False, use_new_attention_order=False, backend="hip", dtype=None):
     """Same keywords as training/openai_util.py:130 (dropout / checkpointing are inference no-ops)."""
     if class_cond:
         raise NotImplementedError("class-conditional UNets are outside the Free Hunch CLI path")
     cm = tuple(int(c) for c in channel_mult.split(",")) if channel_mult else ()
     cfg = UNetConfig(image_size, num_channels, num_res_blocks, cm, learn_sigma, attention_resolutions, num_heads,
                      num_head_channels, use_scale_shift_norm, resblock_updown, use_new_attention_order)
-    return UNetModel(cfg, backend=backend)
+    return UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("bf16" if use_fp16 else "fp32"))
 
 
-def load_model(state_dict_path, setup_path, backend="hip"):
+def load_model(state_dict_path, setup_path, backend="hip", dtype=None):
     """openai_loading_utils.load_model: weights_only state dict + flags text file."""
     sd = torch.load(state_dict_path, map_location="cpu", weights_only=True)
     with open(setup_path) as f:
-        cfg, _fp16 = config_from_setup_text(f.read())
-    model = UNetModel(cfg, backend=backend)
+        cfg, fp16 = config_from_setup_text(f.read())
+    # `use_fp16 True` in the setup file selects the reduced-precision torso, as in the reference (openai_loading_utils.py)
+    model = UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("bf16" if fp16 else "fp32"))
     model.load_state_dict(sd)
     return model, cfg
 

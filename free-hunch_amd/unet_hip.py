@@ -94,6 +94,7 @@ class HipOps:
         self.cfg = cfg
         self.lib = _lib.load()
         self.P = P
+        self.bf16 = False  # reduced-precision torso (UNetModel.set_dtype): convolution operands rounded to bf16
         self.conv = {}
         for k, v in P.items():
             if k.endswith(".weight") and v.dim() >= 3:
@@ -353,6 +354,7 @@ class HipOps:
         cfg = self.cfg
         N, Cin, H, W = x_nchw.shape
         st = _lib.stream()
+        self.lib.fh_unet_set_precision(int(self.bf16))  # process-wide switch of the bf16-MFMA convolution kernels
         x = torch.empty(N, H, W, _pad_to(Cin, _K), dtype=torch.float32, device=x_nchw.device)
         _lib.check(self.lib.fh_layout_nchw_nhwc(x_nchw.contiguous().data_ptr(), x.data_ptr(), N, Cin, H * W, x.shape[-1],
                                                 1, st), "layout")
@@ -391,6 +393,7 @@ class HipOps:
     def backward_tape(self, tape, g_nchw):
         N, Co, H, W = g_nchw.shape
         st = _lib.stream()
+        self.lib.fh_unet_set_precision(int(self.bf16))
         cp = self.conv["out.2"].co_p
         g = torch.empty(N, H, W, cp, dtype=torch.float32, device=g_nchw.device)
         _lib.check(self.lib.fh_layout_nchw_nhwc(g_nchw.contiguous().data_ptr(), g.data_ptr(), N, Co, H * W, cp, 1, st),

@@ -44,10 +44,11 @@ def main(argv=None):
 
     if o.synthetic_weights:
         cfg = {"ffhq": hu.FFHQ256, "imagenet": hu.IMAGENET256}[o.synthetic_weights]
-        model = hu.UNetModel(cfg, backend=o.unet_backend)
+        model = hu.UNetModel(cfg, backend=o.unet_backend, dtype=o.unet_dtype)
         model.load_state_dict(hu.seeded_state(cfg, 0))
     else:
-        model, cfg = hu.load_model(o.openai_state_dict_path, o.openai_setup_path, backend=o.unet_backend)
+        model, cfg = hu.load_model(o.openai_state_dict_path, o.openai_setup_path, backend=o.unet_backend,
+                                   dtype=None if o.unet_dtype == "fp32" else o.unet_dtype)
     net = iDDPMLinearPrecond(model.to(device).eval(), cfg.image_size, 3).to(device)
     S = cfg.image_size
 

@@ -186,6 +186,14 @@ typedef struct fh_problem {
   const int32_t* tap2_dy;
   const int32_t* tap2_dx;
   const double* tap2_w;
+  /* optional: a separable blur folded into the DCT passes that follow / precede it inside A C A^T (use_dct = 1, op = 1).
+   * With A(X) = F_col X F_row^T and P = C_dct F^T:  fold_fwd_w = P_row, fold_fwd_h = P_col  (dct2(A^T u) = P_col u P_row^T),
+   * fold_inv_w = P_row^T, fold_inv_h = P_col^T  (A(idct2(v)) = P_col^T v P_row); each [S][S] float64, row-major.
+   * All four null: the blur runs as tap-list passes.  free-hunch_amd/measurements.py: folded_dct_blur_bases. */
+  const double* fold_fwd_w;
+  const double* fold_fwd_h;
+  const double* fold_inv_w;
+  const double* fold_inv_h;
 } fh_problem;
 
 /* Per-image covariance pointers of a batched solve: B images share the operator, the tap lists, m, ldm and
@@ -246,6 +254,11 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
                    void* stream);
 /* recommended K-split for a layer (1 = none).  With ksplit > 1 the K range is divided over blockIdx.z, raw partial
  * sums go to ws [ksplit][N*Ho*Wo][Cout] (caller-owned) and a second kernel adds them in a fixed order (+ bias, res). */
+/* Precision of the convolution kernels that run on the bf16 matrix cores (fh_conv2d_x6_nhwc, fh_conv2d_x6_norm_nhwc):
+ * 0 (default) = exact 3-way operand split, fp32 accuracy; 1 = plain bf16 compute (operands rounded to bf16, one product,
+ * fp32 accumulation) - the reduced-precision UNet mode, counterpart of the reference's fp16 torso
+ * (training/openai_fp16_util.py:15-32, flag path openai_preconditioning.py:171).  Process-wide. */
+int fh_unet_set_precision(int bf16_compute);
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 
 /* Same convolution as fh_conv2d_nhwc at fp32 accuracy on the bf16 matrix cores: operands are split exactly into three

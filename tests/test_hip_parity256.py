@@ -166,6 +166,53 @@ def test_cov_apply_single_sweep_equals_two_pass_bitwise(dev, S, nimg, m):
         assert float((two_pass[i] - ref).abs().max()) < 1e-10 * float(ref.abs().max())
 
 
+# ---------------------------------------------------------------- a12: separable blur folded into the DCT passes
+@pytest.mark.parametrize("S", [64, 256])
+def test_folded_blur_dct_equals_tap_passes(dev, S, monkeypatch):
+    """A_mm(u) = sigma_y^2 u + A idct2(C dct2(A^T u)) for the Gaussian blur with the DCT prior: the path that folds the two
+    1-D blur passes into the DCT bases (4 dense passes + apply) against the tap-list path (4 blur passes + 4 DCT passes +
+    apply).  Same linear map, different rounding: 1e-12 of max|out|.  Also the whole solve: same iteration count and
+    solution to 1e-9 at a tight tolerance."""
+    import ctypes as C
+    from free_hunch_amd import _lib, covariance as hc
+    from free_hunch_amd.conditioning_mechanisms import _problem, _sigma_y2, solve_customcuda
+    d = 3 * S * S
+    dv = torch.load(os.path.join(DATA, "dct_variance.pt"), weights_only=True)[:, :S, :S].contiguous()
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    torch.save(dv, os.path.join(tmp, "dct_variance.pt"))
+    cov = hc.CovarianceHessianBFGSDCT(tmp, 80.0 ** 2, d, device=dev, use_precalculated_info=True)
+    for what, a in inputs.script(515, (1, 3, S, S), 4, 80.0, sig_end=2.0):
+        if what == "time":
+            cov.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev))
+        else:
+            cov.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+    op = _hip_op("gaussian_blur", S, dev)
+    assert op.folded_bases() is not None
+    u = inputs.randn((1, 3, S, S), 516).to(dev).contiguous()
+    ctx = cov.ctx
+    outs = []
+    for no_fold in ("0", "1"):
+        monkeypatch.setenv("FH_NO_FOLD", no_fold)
+        prob, keep = _problem(op, cov, _sigma_y2(op))
+        assert bool(prob.fold_fwd_w) == (no_fold == "0")
+        out = torch.empty_like(u)
+        _lib.check(ctx.lib.fh_amm(ctx.h, C.byref(prob), u.data_ptr(), out.data_ptr(), _lib.stream()), "amm")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert maxabs(outs[0], outs[1]) < 1e-12 * float(outs[1].abs().max())
+    y = inputs.smooth_image(S, 517).to(dev)
+    x0 = (inputs.smooth_image(S, 518) * 0.9).to(F64).to(dev)
+    sols, infos = [], []
+    for no_fold in ("0", "1"):
+        monkeypatch.setenv("FH_NO_FOLD", no_fold)
+        info = []
+        sols.append(solve_customcuda(op, y, x0, cov, 1.0, 0.3, info, rtol=1e-8))
+        infos.append(info[0])
+    assert infos[0]["niter"] == infos[1]["niter"] and infos[0]["optimal"]
+    assert maxabs(sols[0], sols[1]) < 1e-9 * float(sols[1].abs().max())
+
+
 # ---------------------------------------------------------------- a11-a12 at 256 x 256 (SURVEY 8c item 5)
 @pytest.mark.parametrize("name", ["gaussian_blur", "motion_blur", "super_resolution", "inpainting"])
 def test_solver256_vs_reference_golden(dev, gold, name):

@@ -98,3 +98,27 @@ def test_truncation_bookkeeping_matches_reference_dense_matrices(gold, tag):
             assert np.abs(ref.imag).max() < 1e-9 * max(1.0, np.abs(ref.real).max())
             assert np.abs(rep.dense(B) - ref.real).max() < 1e-8 * max(1.0, np.abs(ref.real).max()), (tag, si, nm)
     assert truncated >= 2
+
+
+def test_folded_dct_blur_bases_equal_blur_then_dct():
+    """Host side of the folded CG operator (free_hunch_amd.measurements.folded_dct_blur_bases): with the circular blur
+    A(X) = F_col X F_row^T given by 1-D tap lists, P_col u P_row^T = dct2(A^T u) and P_col^T v P_row = A(idct2(v)), against
+    SciPy's orthonormal DCT and explicit rolls - asymmetric taps, so that a transposed or mirrored basis cannot pass."""
+    import scipy.fft
+    from free_hunch_amd.measurements import dct_basis_longdouble, folded_dct_blur_bases
+    S = 32
+    g = np.random.default_rng(5)
+    x = g.standard_normal((S, S))
+    C = dct_basis_longdouble(S).astype(np.float64)
+    assert np.abs(C @ x @ C.T - scipy.fft.dctn(x, type=2, norm="ortho")).max() < 1e-13
+    col_dy, row_dx = np.arange(-4, 5), np.arange(-6, 7)
+    cw, rw = g.uniform(0.1, 1.0, 9), g.uniform(0.1, 1.0, 13)
+
+    def blur(X, sign):  # sign = +1: A (out[i] = sum w in[i - d]);  -1: A^T
+        out = sum(w * np.roll(X, sign * int(dd), axis=0) for dd, w in zip(col_dy, cw))
+        return sum(w * np.roll(out, sign * int(dd), axis=1) for dd, w in zip(row_dx, rw))
+
+    P_row, P_col, P_row_t, P_col_t = folded_dct_blur_bases(col_dy, cw, row_dx, rw, S)
+    assert np.abs(P_col @ x @ P_row.T - scipy.fft.dctn(blur(x, -1), type=2, norm="ortho")).max() < 1e-13
+    assert np.abs(P_col_t @ x @ P_row - blur(scipy.fft.idctn(x, type=2, norm="ortho"), +1)).max() < 1e-13
+    assert np.array_equal(P_row_t, P_row.T) and np.array_equal(P_col_t, P_col.T)
