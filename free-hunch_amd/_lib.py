@@ -94,6 +94,8 @@ _SIGS = {
     "fh_concat_channels": ([c_dp, c_dp, c_dp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_layout_nchw_nhwc": ([c_dp, c_dp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_add_f32": ([c_dp, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
+    "fh_metrics_scratch_doubles": ([C.c_int] * 4, C.c_int64),
+    "fh_metrics_u8": ([c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_void_p], C.c_int),
     "fh_cg_solve_batched": ([C.c_void_p, C.POINTER(FhProblem), C.POINTER(FhBatch), c_dp, c_dp, C.POINTER(C.c_double),
                              C.c_double, C.c_int, C.POINTER(FhCgInfo), C.c_void_p], C.c_int),
     "fh_cg_solve": ([C.c_void_p, C.POINTER(FhProblem), c_dp, c_dp, C.c_double, C.c_double, C.c_int,

@@ -40,29 +40,34 @@ def gather_images(local_u8, local_idx, total, device):
     return out
 
 
-def psnr_u8(a, b):
-    mse = ((a.float() - b.float()) ** 2).mean(dim=(1, 2, 3)).clamp_min(1e-12)
-    return 10 * torch.log10(255.0 ** 2 / mse)
-
-
-def ssim_u8(a, b, win_size=7, k1=0.01, k2=0.03):
-    """Mean structural similarity of uint8 image batches [N, C, H, W], the published algorithm with the defaults of
-    `skimage.metrics.structural_similarity(x, y, data_range=255, channel_axis=0)` as the reference calls it
-    (generate_conditional.py:546): 7x7 uniform window, sample covariance (NP / (NP - 1)), K1 = 0.01, K2 = 0.03,
-    float64, the (win_size - 1) / 2 border cropped, mean over pixels then over channels.  scikit-image is not
-    installed in this image, so this is pinned to a scipy.ndimage restatement (tests/test_metrics.py), not to skimage
+def metrics_u8(a, b):
+    """(PSNR [N], SSIM [N]) float64 of uint8 image batches [N, C, H, W] on the device - the reference's per-image metrics
+    (generate_conditional.py:543-551; skimage.metrics.structural_similarity(x, y, data_range=255, channel_axis=0): 7 x 7 uniform
+    window, sample covariance, K1 = 0.01, K2 = 0.03, windows inside the image, mean over positions then channels), one
+    `fh_metrics_u8` call.  LPIPS needs a network download and is not offered.  scikit-image is absent from this image, so
+    the kernel is pinned to a scipy.ndimage restatement of the published algorithm (tests/test_metrics.py), not to skimage
     itself: parity unpinned at that boundary."""
-    x, y = a.to(torch.float64), b.to(torch.float64)
-    n_p = win_size * win_size
-    cov_norm = n_p / (n_p - 1.0)
-    pool = lambda t: torch.nn.functional.avg_pool2d(t, win_size, stride=1)  # 'valid' window means = the cropped region
-    ux, uy = pool(x), pool(y)
-    vx = cov_norm * (pool(x * x) - ux * ux)
-    vy = cov_norm * (pool(y * y) - uy * uy)
-    vxy = cov_norm * (pool(x * y) - ux * uy)
-    c1, c2 = (k1 * 255.0) ** 2, (k2 * 255.0) ** 2
-    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
-    return s.mean(dim=(2, 3)).mean(dim=1)
+    from . import _lib
+    if not (a.is_cuda and b.is_cuda):
+        raise _lib.FhError("metrics_u8 runs on the device (libfh_hip.so); there is no CPU fallback")
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.shape == b.shape and a.dim() == 4
+    lib = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    N, C, H, W = a.shape
+    scratch = torch.empty(int(lib.fh_metrics_scratch_doubles(N, C, H, W)), dtype=torch.float64, device=a.device)
+    ssim = torch.empty(N, dtype=torch.float64, device=a.device)
+    psnr = torch.empty(N, dtype=torch.float64, device=a.device)
+    _lib.check(lib.fh_metrics_u8(a.data_ptr(), b.data_ptr(), N, C, H, W, scratch.data_ptr(), ssim.data_ptr(), psnr.data_ptr(),
+                                 _lib.stream()), "fh_metrics_u8")
+    return psnr, ssim
+
+
+def psnr_u8(a, b):
+    return metrics_u8(a, b)[0]
+
+
+def ssim_u8(a, b):
+    return metrics_u8(a, b)[1]
 
 
 def list_images(path):

@@ -24,7 +24,7 @@ def main(argv=None):
     from free_hunch_amd import unet as hu
     from free_hunch_amd.config import load_config
     from free_hunch_amd.measurements import get_operator
-    from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, psnr_u8, shard_indices, ssim_u8
+    from free_hunch_amd.pipeline import gather_images, list_images, load_image_u8, metrics_u8, shard_indices
     from free_hunch_amd.precond import iDDPMLinearPrecond
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler, conditional_sampler_batched
 
@@ -114,6 +114,14 @@ def main(argv=None):
     unit_ids = [i * ns + o.seeds.index(sd) for i, sd in units]  # global position of (image, seed)
     all_out = gather_images(local_out, unit_ids, total * ns, device)   # the single exchange of the run
     all_cond = gather_images(local_cond, unit_ids, total * ns, device)
+    # metrics as in generate_conditional.py:539-569: per image on the device (fh_metrics_u8), partial sums reduced over ranks
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
+    if local_out.shape[0]:
+        ps, ss = metrics_u8(local_out, local_cond)
+        sums = torch.stack([ps.sum(), ss.sum(), torch.tensor(float(local_out.shape[0]), dtype=torch.float64, device=device)])
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    psnr_mean, ssim_mean = float(sums[0] / sums[2]), float(sums[1] / sums[2])
     name = lambda u: f"{u // ns:06d}_{o.seeds[u % ns]:06d}.png"
     import PIL.Image
     for sub in ("images", "cond_images", "forward_images"):
@@ -125,11 +133,9 @@ def main(argv=None):
             if u % ns == 0:
                 PIL.Image.fromarray(all_cond[u].permute(1, 2, 0).cpu().numpy(), "RGB").save(
                     os.path.join(o.outdir, "cond_images", name(u)))
-        psnr, ssim = psnr_u8(all_out, all_cond), ssim_u8(all_out, all_cond)
         with open(os.path.join(o.outdir, "results.txt"), "w") as f:
-            f.write(f"PSNR: {float(psnr.mean()):.4f}\nSSIM: {float(ssim.mean()):.4f}\nimages: {total * ns}\n")
-        print(f"PSNR {float(psnr.mean()):.3f} dB, SSIM {float(ssim.mean()):.4f} over {total * ns} images -> {o.outdir}",
-              flush=True)
+            f.write(f"PSNR: {psnr_mean:.4f}\nSSIM: {ssim_mean:.4f}\nimages: {total * ns}\n")
+        print(f"PSNR {psnr_mean:.3f} dB, SSIM {ssim_mean:.4f} over {total * ns} images -> {o.outdir}", flush=True)
     for j, u in enumerate(unit_ids):  # forward (measurement) images are written by the owning rank
         if fwds[j].shape[-1] == S:
             PIL.Image.fromarray(fwds[j][0].permute(1, 2, 0).cpu().numpy(), "RGB").save(

@@ -341,6 +341,15 @@ int fh_dense_rank2(const double* A, double* out, int bs, int64_t d, const double
                    const double* a1, const double* u2, const double* v2, const double* a2, double scale, double shift,
                    void* stream);
 
+/* Metrics of the sampling harness (generate_conditional.py:539-551): per-image PSNR and mean structural similarity of
+ * uint8 [N][C][H][W] image batches, the published SSIM with the defaults of skimage.metrics.structural_similarity(x, y,
+ * data_range=255, channel_axis=0) as the reference calls it - 7 x 7 uniform window, sample covariance, K1 = 0.01,
+ * K2 = 0.03, windows that fit the image only, mean over positions then channels.  Window sums in exact integer arithmetic,
+ * map values and means in float64; deterministic.  scratch: fh_metrics_scratch_doubles(N, C, H, W) doubles. */
+int64_t fh_metrics_scratch_doubles(int N, int C, int H, int W);
+int fh_metrics_u8(const uint8_t* a, const uint8_t* b, int N, int C, int H, int W, double* scratch, double* ssim_out,
+                  double* psnr_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
