@@ -7,8 +7,9 @@ Constructor and call signature are the reference's:
         pigdm_posthoc_scaling=False, **kw)           obj(x_t, net, y, sigma) -> x0_mean_new  (float64)
 Differences by design: the covariance state, the trajectory history and every intermediate stay in HBM (the
 reference round-trips them through the CPU each call), and the linear solve is one C-ABI call
-(`fh_cg_solve`) that keeps CG scalars on the device.  Baseline plugins (DPS, PiGDM, TMPD, Peng*, DiffPIR) and
-the scipy solver variants are outside this path and raise NotImplementedError.
+(`fh_cg_solve`) that keeps CG scalars on the device.  The comparison plugins of the reference's registry (DPS, PiGDM, both
+schedules, DiffPIR, Peng-analytic, Peng-convert, TMPD) and its `solver_type` variants (customscipy, scipy) run on the same
+operator / UNet-VJP / CG kernels; only DDNM (a separate sampler) is not here.
 """
 from __future__ import annotations
 
@@ -33,9 +34,6 @@ def choose_conditioning_mechanism(name):
         return BFGSOnlineUpdate
     if name in _BASELINES:
         return _BASELINES[name]
-    if name in ("peng_convert", "tmpd"):
-        raise NotImplementedError(f"'{name}' needs the per-pixel-variance scipy solver of the reference "
-                                  "(conditioning_mechanisms.py:360-381), which is outside this build")
     if name == "ddnm":
         raise ValueError("DDNM conditioning mechanism not implemented in this branch of the codebase")
     raise ValueError(f"Unknown conditioning mechanism: {name}")
@@ -65,6 +63,14 @@ def rtol_func(sigma, rtol_max=1e0, rtol_min=1e-14):
 
 
 _OP_CODE = {"inpainting": 0, "gaussian_blur": 1, "motion_blur": 1, "super_resolution": 2}
+
+
+def rtol_func_2(sigma, rtol_max=1e0, rtol_min=1e-4):
+    """Tolerance schedule of the reference's scipy solvers when `use_rtol_func` is set (TMPD), :325-343."""
+    lo, hi = 0.1, 80.0
+    sigma = max(min(sigma, hi), max(lo, sigma))
+    frac = ((math.log10(sigma) - math.log10(lo)) / (math.log10(hi) - math.log10(lo))) ** 0.05
+    return 10 ** (frac * (math.log10(rtol_max) - math.log10(rtol_min)) + math.log10(rtol_min))
 
 
 def _problem(operator, cov, sigma_y2):
@@ -106,8 +112,10 @@ def _sigma_y2(operator):
     return float((s ** 2).item())
 
 
-def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out=None, rtol=None):
-    """mat = A^T (A C A^T + sigma_y^2 I)^-1 (y - A x0_mean), float64, on the device."""
+def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out=None, rtol=None, scipy_cg=False):
+    """mat = A^T (A C A^T + sigma_y^2 I)^-1 (y - A x0_mean), float64, on the device.  `scipy_cg`: iterate like
+    scipy.sparse.linalg.cg as the reference's scipy solver variants call it (x0 = 0, initial residual tested first,
+    maxiter 1000) instead of like its own cg() (x0 = b, maxiter 5000)."""
     cov = covariance_model
     ctx = cov.ctx
     dev = cov.device
@@ -116,6 +124,7 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
         raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
                          "'motion_blur', or 'inpainting'.")
     prob, keep = _problem(operator, cov, _sigma_y2(operator))
+    prob.cg_scipy = int(bool(scipy_cg))
     y64 = y.detach().to(device=dev, dtype=F64).contiguous()
     x64 = x0_mean.detach().to(device=dev, dtype=F64).contiguous()
     # b = y - A x0_mean
@@ -128,9 +137,10 @@ def solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, 
     sol = torch.empty_like(b)
     info = _lib.FhCgInfo()
     rtol = rtol_func(sigma_t, max_rtol) if rtol is None else rtol
-    _lib.check(ctx.lib.fh_cg_solve(ctx.h, C.byref(prob), b.data_ptr(), sol.data_ptr(), rtol, 0.0, 5000,
+    maxiter = 1000 if scipy_cg else 5000
+    _lib.check(ctx.lib.fh_cg_solve(ctx.h, C.byref(prob), b.data_ptr(), sol.data_ptr(), rtol, 0.0, maxiter,
                                    C.byref(info), _lib.stream()), "fh_cg_solve")
-    if info.niter == (5000 if name == "inpainting" else 2000):  # the reference's (inconsistent) guards
+    if info.niter == (1000 if scipy_cg else (5000 if name == "inpainting" else 2000)):  # the reference's (inconsistent) guards
         warn("CG not converge.")
     if info_out is not None:
         info_out.append({"niter": info.niter, "optimal": bool(info.optimal), "residual_norm": info.residual_norm,
@@ -215,9 +225,19 @@ def choose_solver(operator_name, operator, y, x0_mean, theta0_var=None, covarian
     if operator_name not in _OP_CODE:
         raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
                          "'motion_blur', or 'inpainting'.")
-    if method != "customcuda":
-        raise NotImplementedError(f"solver_type='{method}' (scipy CPU solvers) is outside the MI355X hot path")
-    return solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out)
+    if method == "customcuda":
+        return solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out)
+    # The reference's two scipy variants run `scipy.sparse.linalg.cg` on the CPU in float32 with tol = 1e-4 (or rtol_func_2
+    # when use_rtol_func) and maxiter 1000 (:360-381, :420-447, :449-484, :529-560, :602-639, :677-706).  Same linear systems
+    # on the device CG here in its scipy mode (fh_problem.cg_scipy: x0 = 0, initial residual tested first, no pAp test), in
+    # float64 where the reference's LinearOperator is float32.
+    tol = 1e-4 if (sigma_t is None or not use_rtol_func) else rtol_func_2(float(sigma_t))
+    if method == "customscipy":  # the Free Hunch covariance with scipy's tolerance rule
+        return solve_customcuda(operator, y, x0_mean, covariance_model, max_rtol, sigma_t, info_out, rtol=tol, scipy_cg=True)
+    if method == "scipy":        # scalar or per-pixel variance theta0_var in image space (no DCT)
+        data_dim = int(np.prod(operator.in_shape[1:]))
+        return _variance_mat(operator, y, x0_mean, theta0_var, data_dim, tol, info_out)
+    raise ValueError(f"unknown solver_type '{method}' (customcuda, customscipy, scipy)")
 
 
 # ---------------------------------------------------------------------------------------------- the plugin
@@ -253,6 +273,10 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self.space_step_update_lower_threshold = argv["space_step_update_lower_threshold"]
         self.pigdm_posthoc_scaling = pigdm_posthoc_scaling
         self.use_analytic_var_at_end = argv.get("use_analytic_var_at_end", False)
+        self.use_rtol_func = argv.get("use_rtol_func", False)
+        if self.solver_type == "scipy":
+            raise ValueError("solver_type=scipy solves with a scalar / per-pixel variance; online_covariance needs "
+                             "customcuda or customscipy")
         # the reference loads this file unconditionally (:225-226)
         self.recon_mse = torch.load(os.path.join(_DATA, "recon_mse.pt"), weights_only=True)
         self.mle_sigma_thres = 0.2
@@ -291,7 +315,7 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             return mat
         mat = choose_solver(self.forward_operator.name, self.forward_operator, y, m_det,
                             covariance_model=self.covariance_model, method=self.solver_type, max_rtol=self.max_rtol,
-                            sigma_t=float(sigma), info_out=info)
+                            sigma_t=float(sigma), use_rtol_func=self.use_rtol_func, info_out=info)
         self._rec = dict(info[0])
         return mat
 
@@ -351,6 +375,21 @@ def _scalar_mat(operator, y, x0_mean, theta, data_dim):
     return solve_customcuda(operator, y, x0_mean.detach(), scal, 1.0, 1.0, None, rtol=1e-10)
 
 
+def _variance_mat(operator, y, x0_mean, theta, data_dim, rtol=1e-4, info_out=None):
+    """mat = A^T (sigma_y^2 I + A diag(theta) A^T)^-1 (y - A x0) for a scalar or PER-PIXEL image-space variance theta
+    (`_inpainting_mat` / `_deblur_mat` / `_super_resolution_mat`, :353-382, :449-484, :602-639).  A scalar goes through the
+    closed form's system at 1e-10; a per-pixel field is the reference's scipy-CG branch, here the device CG with the
+    covariance representation D = theta, no factor columns, identity basis."""
+    theta = torch.as_tensor(theta)
+    if theta.numel() == 1:
+        return _scalar_mat(operator, y, x0_mean, theta, data_dim)
+    cov = ScalarCovariance(1.0, data_dim, x0_mean.device, getattr(operator, "ctx_slot", 0))
+    cov.C.D = theta.detach().to(device=x0_mean.device, dtype=F64).reshape(-1).contiguous()
+    if cov.C.D.numel() != data_dim:
+        raise ValueError(f"per-pixel variance has {cov.C.D.numel()} entries, expected {data_dim}")
+    return solve_customcuda(operator, y, x0_mean.detach(), cov, 1.0, 1.0, info_out, rtol=rtol, scipy_cg=True)
+
+
 class _ScalarVarianceMechanism(ConditioningMechanism):
     def __init__(self, cond_scaling, forward_operator, clip_x0_mean, init_denoiser_variance=None,
                  init_noise_variance=None, data_dim=None, pigdm_posthoc_scaling=True, **argv):
@@ -400,6 +439,30 @@ class PengAnalytic(_ScalarVarianceMechanism):  # :87-110
         return sigma.pow(2) / (1 + sigma.pow(2))
 
 
+class PengConvert(_ScalarVarianceMechanism):  # :64-85 - the network's learned per-pixel variance below sigma = 0.2
+    def x0_mean_update(self, x_t, model, y, sigma):
+        x_t = x_t.requires_grad_()
+        x_0_mean, x0_var = model(x_t, sigma)
+        if not bool(sigma < self.mle_sigma_thres):
+            x0_var = sigma.pow(2) / (1 + sigma.pow(2))
+        mat = _variance_mat(self.forward_operator, y, x_0_mean, x0_var.detach(), self.data_dim, 1e-4)
+        p_y_xt_grad = grad((mat.detach() * x_0_mean).sum(), x_t)[0] * self.cond_scaling
+        return x_0_mean + p_y_xt_grad * sigma.pow(2)
+
+
+class TMPD(_ScalarVarianceMechanism):  # :112-133 - variance from the row sums of the denoiser Jacobian
+    def x0_mean_update(self, x_t, model, y, sigma):
+        x_t = x_t.requires_grad_()
+        x_0_mean_, _ = model(x_t, sigma)
+        x0_var = grad(x_0_mean_.sum(), x_t)[0] * sigma.pow(2)
+        mat = _variance_mat(self.forward_operator, y, x_0_mean_.detach(), x0_var.detach(), self.data_dim,
+                            rtol_func_2(float(sigma)))
+        x_t = x_t.detach().requires_grad_()
+        x_0_mean, _ = model(x_t, sigma)
+        p_y_xt_grad = grad((mat.detach() * x_0_mean).sum(), x_t)[0] * self.cond_scaling
+        return x_0_mean + p_y_xt_grad * sigma.pow(2)
+
+
 class DiffPIR(ConditioningMechanism):  # :173-188
     def __init__(self, cond_scaling, forward_operator, clip_x0_mean, **argv):
         super().__init__(cond_scaling, forward_operator, clip_x0_mean)
@@ -430,4 +493,4 @@ class DPS(ConditioningMechanism):  # :52-63
 
 
 _BASELINES = {"dps": DPS, "pigdm": PiGDM, "pigdm_videodiff_schedule": PiGDM_Videodiff_schedule,
-              "peng_analytic": PengAnalytic, "diffpir": DiffPIR}
+              "peng_analytic": PengAnalytic, "peng_convert": PengConvert, "tmpd": TMPD, "diffpir": DiffPIR}

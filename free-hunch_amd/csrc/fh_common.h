@@ -42,6 +42,7 @@ struct fh_cg_state {  // device-resident control block of the CG loop
   int it;        // completed iterations (device-side loop counter: the iteration body is graph-replayable)
   int k_cur;     // iteration in flight, written by step 1, consumed by step 2
   int maxiter;
+  int scipy_mode;  // fh_problem.cg_scipy of the running solve
 };
 
 struct fh_graph_entry {  // one instantiated chunk-of-iterations graph, keyed by the problem it was captured for

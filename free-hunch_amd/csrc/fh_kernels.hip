@@ -1448,14 +1448,15 @@ __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, c
                                                  double* __restrict__ p, double* __restrict__ part, int64_t n) {
   {
     const int64_t off = (int64_t)blockIdx.z * n;
-    b += off, Ab += off, x += off, r += off, p += off;
+    b += off, x += off, r += off, p += off;
+    if (Ab != nullptr) Ab += off;
     part += (int64_t)blockIdx.z * kCgScratch;
   }
   __shared__ double red[4];
   double srr = 0.0, sbb = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double bi = b[i], ri = bi - Ab[i];
-    x[i] = bi;
+    const double bi = b[i], ri = Ab != nullptr ? bi - Ab[i] : bi;  // Ab == null: x0 = 0 (scipy's start), r = b
+    x[i] = Ab != nullptr ? bi : 0.0;
     r[i] = ri;
     p[i] = ri;
     srr = fma(ri, ri, srr);
@@ -1471,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b, c
 
 __global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ part, int nparts, RtolArr rtols,
                                                      double atol, int maxiter, fh_cg_state* __restrict__ stt,
-                                                     double* __restrict__ rzbuf) {
+                                                     double* __restrict__ rzbuf, int scipy_mode) {
   const double rtol = rtols.v[blockIdx.z];
   part += (int64_t)blockIdx.z * kCgScratch;
   rzbuf += (int64_t)blockIdx.z * kCgScratch;
@@ -1492,6 +1493,11 @@ __global__ __launch_bounds__(256) void k_cg_init_fin(const double* __restrict__ 
     stt->it = 0;
     stt->k_cur = 0;
     stt->maxiter = maxiter;
+    stt->scipy_mode = scipy_mode;
+    if (scipy_mode && sqrt(srr) <= stt->stop) {  // scipy tests the initial residual before the first iteration
+      stt->optimal = 1;
+      stt->done = 1;
+    }
   }
 }
 
@@ -1515,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_cg_step1(const double* __restrict__ p, 
   }
   __shared__ double red[4];
   const double pAp = sum_partials(part_pap, nparts, red);
-  if (pAp <= 1e-16) {  // cg.py:250 - also catches NaN-free breakdowns; x, r keep their previous values
+  if (stt->scipy_mode ? pAp == 0.0 : pAp <= 1e-16) {  // cg.py:250 (scipy has no such test: only an exact zero stops it here)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       stt->pAp = pAp;
       stt->niter = k;
@@ -2022,12 +2028,16 @@ int fh_cg_solve_batched(fh_context* ctx, const fh_problem* p, const fh_batch* pe
   for (int i = 0; i < FH_MAX_BATCH; ++i) rt.v[i] = i < nimg ? rtol_host[i] : 1.0;
   for (int i = 0; i < nimg; ++i)
     if (!(rtol_host[i] > 0 || atol > 0)) return FH_EINVAL;
-  int rc = amm_launch(ctx, p, per, b, ap, nullptr, st);  // A x0 with x0 = b
-  if (rc) return rc;
+  int rc = 0;
+  if (!p->cg_scipy) {
+    rc = amm_launch(ctx, p, per, b, ap, nullptr, st);  // A x0 with x0 = b
+    if (rc) return rc;
+  }
   const dim3 grid(kCgBlocks, 1, (unsigned)nimg);
-  hipLaunchKernelGGL(k_cg_init, grid, dim3(256), 0, st, b, (const double*)ap, ctx->cg_x, r, pk, part, n);
+  hipLaunchKernelGGL(k_cg_init, grid, dim3(256), 0, st, b, p->cg_scipy ? (const double*)nullptr : (const double*)ap, ctx->cg_x,
+                     r, pk, part, n);
   hipLaunchKernelGGL(k_cg_init_fin, dim3(1, 1, (unsigned)nimg), dim3(256), 0, st, (const double*)part, kCgBlocks, rt,
-                     atol, maxiter, stt, rzbuf);
+                     atol, maxiter, stt, rzbuf, (int)p->cg_scipy);
   const int chunk = 8;
   hipGraphExec_t exec = cg_graph_for(ctx, p, per, n, chunk, st);
   fh_cg_state* h = ctx->h_state;  // pinned: the periodic read-back is a true async copy

@@ -183,6 +183,12 @@ typedef struct fh_problem {
   /* optional second pass of a separable PSF (k = col (x) row): A = conv(tap2) o conv(tap), ntaps2 = 0 when unused */
   int32_t ntaps2;
   int32_t halo2;
+  /* 0: the reference's cg() (conditioning_utils/cg.py:118-292: x0 = b, stop checked after every iteration, break at
+   * pAp <= 1e-16) - the customcuda solvers.  1: scipy.sparse.linalg.cg as the reference's scipy / customscipy solver
+   * variants call it (x0 = 0, the initial residual is tested first - tol >= 1 returns 0 without iterating - and no pAp
+   * test; conditioning_mechanisms.py:379, 444, 474, 548, 630, 696). */
+  int32_t cg_scipy;
+  int32_t reserved0;
   const int32_t* tap2_dy;
   const int32_t* tap2_dx;
   const double* tap2_w;

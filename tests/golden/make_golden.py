@@ -59,12 +59,21 @@ def _install_standins():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
 
+def _scipy_cg_tol_shim(ref_cm):
+    """The reference pins scipy==1.11.4 and calls `scipy.sparse.linalg.cg(A, b, tol=..., maxiter=...)` in its scipy solver
+    variants; this image has scipy 1.15, where that keyword is `rtol` (same meaning: stop at ||r|| <= tol ||b||, which is also
+    what 1.11's default atol='legacy' evaluates to).  Only the keyword is translated."""
+    import scipy.sparse.linalg
+    ref_cm.cg = lambda A, b, tol=1e-5, maxiter=None: scipy.sparse.linalg.cg(A, b, rtol=tol, maxiter=maxiter)
+
+
 _install_standins()
 warnings.filterwarnings("ignore")
 import conditioning_utils.online_update_bfgs as ref_cov  # noqa: E402
 
 ref_cov.CovarianceHessianBFGSDCTPCA = type("CovarianceHessianBFGSDCTPCA", (), {})
 import conditioning_utils.conditioning_mechanisms as ref_cm  # noqa: E402
+_scipy_cg_tol_shim(ref_cm)
 import conditioning_utils.cg as ref_cg  # noqa: E402
 import generate_conditional as ref_gc  # noqa: E402
 import measurement_utils.measurements as ref_meas  # noqa: E402
@@ -519,6 +528,16 @@ def gold_traj(size=64, cfg=SMALL_A, unet_seed=11, cases=TRAJ_CASES_64, seed_base
         trace.append({"niter": info["niter"]})
         return sol, info
 
+    orig_scipy_cg = ref_cm.cg
+
+    def rec_scipy_cg(A, b, tol=1e-5, maxiter=None):  # solver_type=customscipy: count iterations through the callback
+        import scipy.sparse.linalg
+        cnt = [0]
+        sol, info = scipy.sparse.linalg.cg(A, b, rtol=tol, maxiter=maxiter,
+                                           callback=lambda xk: cnt.__setitem__(0, cnt[0] + 1))
+        trace.append({"niter": cnt[0], "dot_base": 0, "tol": float(tol)})  # scipy starts from 0: no initial A x0
+        return sol, info
+
     def rec_get_op(**kw):
         holder["op"] = orig_get_op(**kw)
         return holder["op"]
@@ -539,13 +558,14 @@ def gold_traj(size=64, cfg=SMALL_A, unet_seed=11, cases=TRAJ_CASES_64, seed_base
             cm.denoiser_cov_vector_dot = orig_dot
             rec = trace[n_before]
             # CG calls the dot niter+1 times (initial residual + one per iteration); one more = the cov branch
-            rec["branch_cov"] = int(calls["n"] > rec["niter"] + 1)
+            rec["branch_cov"] = int(calls["n"] > rec["niter"] + rec.get("dot_base", 1))
             rec["k"] = cm.vectors_denoiser_cov_u.shape[-1]
             rec["sigma"] = float(sigma)
             rec["out_sum"] = float(out.detach().double().sum())
             return out
 
     ref_cm.torch_cg.cg = rec_cg
+    ref_cm.cg = rec_scipy_cg
     ref_gc.get_operator = rec_get_op
     ref_gc.choose_conditioning_mechanism = lambda name: Recorder
     out = {"cfg": cfg_dict(cfg), "unet_seed": unet_seed}
@@ -588,6 +608,7 @@ def gold_traj(size=64, cfg=SMALL_A, unet_seed=11, cases=TRAJ_CASES_64, seed_base
         print(tag, "calls", len(trace), "niter sum", int(np.sum(out[p + "niter"])), "k", out[p + "k"][-1],
               "cov-branch", int(np.sum(out[p + "branch_cov"])))
     ref_cm.torch_cg.cg, ref_gc.get_operator, ref_gc.choose_conditioning_mechanism = orig_cg, orig_get_op, orig_choose
+    ref_cm.cg = orig_scipy_cg
     save(name, **out)
 
 
@@ -606,11 +627,19 @@ BASELINE_CASES = [
     ("diffpir_mb", "diffpir", "motion_blur", "heun", 10, {"diffpir_lambda": 7.0}),
     ("peng_analytic_gb", "peng_analytic", "gaussian_blur", "heun", 10, {}),
 ]
+# the per-pixel-variance plugins (scipy solver branch of the reference); separate file baselines_perpixel.npz
+PERPIXEL_CASES = [
+    ("tmpd_gb", "tmpd", "gaussian_blur", "heun", 8, {"clip_x0_mean": True}),
+    ("tmpd_ip", "tmpd", "inpainting", "euler", 10, {"clip_x0_mean": True}),
+    ("pengconvert_sr", "peng_convert", "super_resolution", "heun", 8, {"clip_x0_mean": True}),
+    ("pengconvert_gb", "peng_convert", "gaussian_blur", "euler", 10, {"clip_x0_mean": True}),
+]
 
 
-def gold_baselines():
+def gold_baselines(cases=None, name="baselines", seed_base=140):
     """DPS / PiGDM / PiGDM (video-diffusion schedule) / DiffPIR / Peng-analytic through the reference's own
     conditional_sampler on the small UNet: final image and the per-call sum of the returned x0 estimate."""
+    cases = BASELINE_CASES if cases is None else cases
     size = 64
     net = ref_net(SMALL_A, 11)
     base = dict(cond_scaling=1.0, clip_x0_mean=False, pigdm_posthoc_scaling=False, max_vector_count=100000,
@@ -637,16 +666,16 @@ def gold_baselines():
     ref_gc.choose_conditioning_mechanism = lambda name: recording(orig_choose(name))
     out = {"cfg": cfg_dict(SMALL_A), "unet_seed": 11}
     try:
-        for ci, (tag, mech, opname, solver, nsteps, over) in enumerate(BASELINE_CASES):
-            x0 = smooth_image(size, 140 + ci)
-            noise = randn((1, 3, size, size), 150 + ci, torch.float32)
+        for ci, (tag, mech, opname, solver, nsteps, over) in enumerate(cases):
+            x0 = smooth_image(size, seed_base + ci)
+            noise = randn((1, 3, size, size), seed_base + 10 + ci, torch.float32)
             op_kw = dict(name=opname, device=torch.device("cpu"), sigma_s=0.1, kernel_size=61, intensity=1.0,
                          scale_factor=4, in_shape=(1, 3, size, size),
                          mask_opt={"mask_type": "random", "mask_len_range": (64, 156),
                                    "mask_prob_range": (0.6, 0.8), "image_size": size})
             sums.clear()
-            np.random.seed(160 + ci)
-            torch.manual_seed(160 + ci)
+            np.random.seed(seed_base + 20 + ci)
+            torch.manual_seed(seed_base + 20 + ci)
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):
@@ -654,7 +683,7 @@ def gold_baselines():
                     net, noise, x0.clone(), op_kw, {}, num_steps=nsteps, sigma_min=0.002, sigma_max=80, rho=7,
                     solver=solver, **{**base, "conditioning_mechanism": mech, **over})
             p = tag + "__"
-            out.update({p + "seeds": np.array([140 + ci, 150 + ci]), p + "y": y, p + "x_final": x_final,
+            out.update({p + "seeds": np.array([seed_base + ci, seed_base + 10 + ci]), p + "y": y, p + "x_final": x_final,
                         p + "mech": np.array(mech), p + "op": np.array(opname), p + "solver": np.array(solver),
                         p + "num_steps": nsteps, p + "over": np.array(repr(over)), p + "out_sum": np.array(sums)})
             if opname == "inpainting":
@@ -662,7 +691,19 @@ def gold_baselines():
             print(tag, "calls", len(sums), "final range", float(x_final.min()), float(x_final.max()))
     finally:
         ref_gc.get_operator, ref_gc.choose_conditioning_mechanism = orig_get_op, orig_choose
-    save("baselines", **out)
+    save(name, **out)
+
+
+def gold_perpixel():
+    gold_baselines(PERPIXEL_CASES, "baselines_perpixel", seed_base=340)
+
+
+def gold_traj_extra():
+    """`solver_type=customscipy` (the Free Hunch covariance behind the reference's scipy CG, tol 1e-4 / rtol_func_2)."""
+    gold_traj(cases=[("sr_heun10_customscipy", "super_resolution", "heun", 10, {"solver_type": "customscipy"}),
+                     ("ip_euler12_customscipy_rtol", "inpainting", "euler", 12,
+                      {"solver_type": "customscipy", "use_rtol_func": True})],
+              seed_base=440, name="trajectories_extra")
 
 
 if __name__ == "__main__":
@@ -671,4 +712,5 @@ if __name__ == "__main__":
     for w in which:
         {"sigma": gold_sigma, "unet": gold_unet, "cov": gold_cov, "ops": gold_ops, "solver": gold_solver,
          "traj": gold_traj, "dense": gold_dense, "baselines": gold_baselines, "cov_trunc": gold_cov_trunc,
-         "cov256": gold_cov256, "solver256": gold_solver256, "traj256": gold_traj256}[w]()
+         "cov256": gold_cov256, "solver256": gold_solver256, "traj256": gold_traj256, "perpixel": gold_perpixel,
+         "traj_extra": gold_traj_extra}[w]()

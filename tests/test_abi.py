@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from free_hunch_amd import _lib
-    assert ctypes.sizeof(_lib.FhProblem) == 8 * 4 + 8 + 8 + 8 * 8 + 8 + 3 * 8 + 4 * 8 and _lib.FhProblem.fold_fwd_w.offset == 144
+    assert ctypes.sizeof(_lib.FhProblem) == 8 * 4 + 8 + 8 + 8 * 8 + 16 + 3 * 8 + 4 * 8 and _lib.FhProblem.fold_fwd_w.offset == 152
     assert _lib.FhProblem.d.offset == 32 and _lib.FhProblem.sigma_y2.offset == 40
     assert _lib.FhProblem.tap_dy.offset == 48 and _lib.FhProblem.M.offset == 104
     # struct fh_cov_state: int64 d, 6 x int32, 3 x (4 pointers), 7 pointers

@@ -46,6 +46,6 @@ def test_cli_comparison_method(tmp_path):
              "--max_batch_size=1", "--operator_name=gaussian_blur", "--solver=euler", "--conditioning_mechanism=pigdm"])
     txt = open(out / "results.txt").read()
     assert "PSNR" in txt and "SSIM" in txt
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # DDNM is a separate sampler in the reference, not on this path
         gc.main([f"--outdir={out}", f"--dataset_path={data}", "--synthetic_weights=ffhq", "--num_steps=3",
-                 "--total_images=1", "--conditioning_mechanism=tmpd"])
+                 "--total_images=1", "--conditioning_mechanism=ddnm"])

@@ -22,8 +22,8 @@ def test_registry_errors_match_reference():
         choose_conditioning_mechanism("no_such_mechanism")
     with pytest.raises(ValueError):                                              # DDNM branch :34
         choose_conditioning_mechanism("ddnm")
-    with pytest.raises(NotImplementedError):                                     # per-pixel-variance methods: out of scope
-        choose_conditioning_mechanism("tmpd")
+    assert choose_conditioning_mechanism("tmpd").__name__ == "TMPD"              # per-pixel-variance methods
+    assert choose_conditioning_mechanism("peng_convert").__name__ == "PengConvert"
     assert choose_conditioning_mechanism("dps").__name__ == "DPS"                # scalar-variance comparison methods
     assert choose_conditioning_mechanism("pigdm").__name__ == "PiGDM"
     with pytest.raises(NameError, match="is not defined"):                       # measurements.py:37-40
