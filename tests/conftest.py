@@ -13,6 +13,11 @@ for p in (ROOT, GOLD):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle side of the GPU tests works on 64^2 .. 256^2 images: on the GPU box's 128 logical CPUs the default
+    # thread count spends its time in barriers (a 256^2 teacher-forced run went from minutes to > 5 min); 32 is the sweet spot
+    import torch
+    if torch.cuda.is_available() and (os.cpu_count() or 1) > 32:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")
