@@ -153,9 +153,9 @@ def test_perpixel_variance_plugins_vs_reference_golden(dev, gold, tag, tmp_path)
         # TMPD's variance field (row sums of the Jacobian of a RANDOM-weight UNet, times sigma^2) has entries of both
         # signs, so sigma_y^2 I + A diag(theta) A^T is indefinite and CG - scipy's float32 one in the recording, the float64
         # one here - is not solving a well-posed problem: its iterates depend on rounding.  What is comparable: the calls
-        # where scipy returns before iterating (tol = rtol_func_2(sigma) >= 1 at sigma = 80: mat = 0), which pin the plugin's
+        # where scipy returns before iterating (tol = rtol_func_2(sigma) >= 1 at sigma = 80: mat = 0 - the first call), which pins the plugin's
         # own arithmetic (two UNet passes, the Jacobian row sums, the update), to 1e-5; the rest is reported.
-        assert float(dev_sums[:2].max()) < 1e-5, dev_sums
+        assert float(dev_sums[0]) < 1e-5, dev_sums
         return
     assert float(dev_sums.max()) < 5e-4, dev_sums   # float64 device CG vs the reference's float32 scipy CG, tol 1e-4
     assert err < 1e-3, err                          # north-star tolerance on the final image
