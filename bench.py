@@ -149,14 +149,17 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 1e3 / iters
 
-    # The launch the samplers issue: the lock-step CG (and the single-image sampler) run alone on the GPU, so their context
-    # is declared exclusive and the apply is ONE kernel that keeps the factor base in registers between the reduction and
-    # the product (k_rep_fused).  The two-pass kernels (concurrent per-image streams) are timed beside it.
-    ctx.set_exclusive(True)
+    # What the samplers issue: their contexts are exclusive (nothing else synchronises across workgroups on the GPU), which
+    # selects the single-sweep kernel (k_rep_fused: B stays in registers between the reduction and the product) for
+    # single-image launches and the two-pass kernels for batched ones (the single sweep is slower there:
+    # profiles/r02_cov_apply_single_sweep.md).  The other variant is timed beside it.
+    ctx.set_exclusive(1)
     sec = timed()
     ctx.status()
-    ctx.set_exclusive(False)
-    sec2 = timed()
+    ctx.set_exclusive(0 if nimg == 1 else 2)
+    sec_alt = timed()
+    ctx.status()
+    ctx.set_exclusive(0)
     algo_bytes = nimg * (8 * d * m + 8 * d * 4)  # per image: base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
     traffic = None  # HBM-side bytes per apply from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
@@ -164,15 +167,16 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
     if m == 32 and nimg in (1, 8) and os.path.exists(pmc):
         with open(pmc) as f_:
             traffic = json.load(f_).get("traffic_bytes_per_apply")
-    return {"bound": "hbm", "kernel": f"fh_rep_apply = k_rep_fused<4> (single sweep; d=196608, m={m}, f64, "
-                                      f"{nimg} image{'s' if nimg > 1 else ''} per launch)",
+    two_pass, fused = "k_rep_dots + k_rep_coef + k_rep_apply2 (two sweeps of B)", "k_rep_fused<4> (single sweep: B read once)"
+    return {"bound": "hbm", "kernel": f"fh_rep_apply = {fused if nimg == 1 else two_pass}; d=196608, m={m}, f64, "
+                                      f"{nimg} image{'s' if nimg > 1 else ''} per launch",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2),
-            "two_pass_kernels": {"kernel": "k_rep_dots + k_rep_coef + k_rep_apply2 (non-exclusive contexts)",
-                                 "achieved": round(algo_bytes / sec2 / 1e9, 1), "unit": "GB/s",
-                                 "frac": round(algo_bytes / sec2 / 1e9 / HBM_PEAK_GBS, 4),
-                                 "us_per_apply": round(sec2 * 1e6, 2)}}
+            "other_variant": {"kernel": two_pass if nimg == 1 else fused,
+                              "achieved": round(algo_bytes / sec_alt / 1e9, 1), "unit": "GB/s",
+                              "frac": round(algo_bytes / sec_alt / 1e9 / HBM_PEAK_GBS, 4),
+                              "us_per_apply": round(sec_alt * 1e6, 2)}}
 
 
 def roofline_dense_cov_apply(device, d=12288, iters=30):

@@ -19,7 +19,7 @@ class FhProblem(C.Structure):
                 ("d", C.c_int64), ("sigma_y2", C.c_double),
                 ("tap_dy", c_dp), ("tap_dx", c_dp), ("tap_w", c_dp), ("mask", c_dp),
                 ("D", c_dp), ("r", c_dp), ("B", c_dp), ("M", c_dp),
-                ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("cg_scipy", C.c_int32), ("reserved0", C.c_int32),
+                ("ntaps2", C.c_int32), ("halo2", C.c_int32), ("cg_scipy", C.c_int32), ("fold_sym", C.c_int32),
                 ("tap2_dy", c_dp), ("tap2_dx", c_dp), ("tap2_w", c_dp),
                 ("fold_fwd_w", c_dp), ("fold_fwd_h", c_dp), ("fold_inv_w", c_dp), ("fold_inv_h", c_dp)]
 

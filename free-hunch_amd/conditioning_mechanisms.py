@@ -99,8 +99,10 @@ def _problem(operator, cov, sigma_y2):
         p.tap_dy, p.tap_dx, p.tap_w = t.dy.data_ptr(), t.dx.data_ptr(), t.w.data_ptr()
         fold = operator.folded_bases() if (cov.use_dct and p.op == 1) else None
         if fold is not None:  # separable blur absorbed by the DCT passes of A C A^T (measurements.folded_dct_blur_bases)
-            p.fold_fwd_w, p.fold_fwd_h, p.fold_inv_w, p.fold_inv_h = (f.data_ptr() for f in fold)
-            keep.extend(fold)
+            mats, sym = fold
+            p.fold_fwd_w, p.fold_fwd_h, p.fold_inv_w, p.fold_inv_h = (f.data_ptr() for f in mats)
+            p.fold_sym = int(sym)
+            keep.extend(mats)
     return p, keep
 
 

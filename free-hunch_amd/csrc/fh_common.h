@@ -59,6 +59,8 @@ struct fh_context {
   int nimg_max;       // images a batched call may carry = max(1, planes_max / 3)
   double* basis;      // [S][S]  C[k][n] = s_k cos(pi (2n+1) k / 2S)
   double* basis_t;    // [S][S]  transpose
+  double* sym_fwd;    // [2][S/2][S/2] packed half bases of the symmetric forward passes (null unless S % 64 == 0)
+  double* sym_inv;    // [2][S/2][S/2] the same for the inverse passes
   double* tmp_img;    // [planes_max*S*S] DCT intermediate
   double* partial;    // [kPartialRows][FH_MAX_COLS] block partials (dots) / scalar partials
   double* gpartial;   // Gram partials

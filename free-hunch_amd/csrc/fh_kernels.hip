@@ -161,14 +161,185 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Symmetric-basis form of the DCT passes (k_dct_sym).  Both dense passes are written as the SAME per-plane product with a
+// transposed result,  out[k][r] = sum_n P[k][n] in[r][n]:  pass A gives (X P_w^T)^T, pass B applied to that gives
+// P_h X P_w^T in the natural orientation.  The DCT basis - and a symmetric blur folded into it - satisfies
+// P[k][S-1-n] = (-1)^k P[k][n], so with the butterflies s = x_n + x_{S-1-n}, d = x_n - x_{S-1-n}
+//     forward  (INV = 0):  out[2j][r] = sum_{n<S/2} Pe[j][n] s[r][n],   out[2j+1][r] = sum_{n<S/2} Po[j][n] d[r][n]
+//     inverse  (INV = 1, basis Q = P^T, mirror symmetry in k):  E = sum_j Qe[k][j] x[r][2j],  O = sum_j Qo[k][j] x[r][2j+1],
+//                          out[k][r] = E + O,  out[S-1-k][r] = E - O          (k < S/2)
+// half the multiply-adds of the dense pass.  A workgroup owns 32 (j or k) x 32 (r) outputs of each parity, keeps its two
+// half-basis slices (2 x 32 x S/2 doubles, 66 KB at S = 256) RESIDENT in LDS and walks over its share of the planes, so per
+// output tile it pulls 85 KB from L2 instead of the 192 KB of the 64 x 32 dense tile (the dense kernel is bound by the
+// ~12 B/clk a CU pulls from L2, not by the f64 matrix cores).  Same MFMA (v_mfma_f64_16x16x4_f64), same LDS row pitch rule.
+// ------------------------------------------------------------------------------------------------
+template <bool INV>
+__global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, const double* __restrict__ X,
+                                                 double* __restrict__ C, int S, int planes,
+                                                 const fh_cg_state* __restrict__ states, const double* __restrict__ add,
+                                                 double add_scale) {
+  constexpr int TJ = 32, TR = 32, BK = 32, LDB = BK + 2, NBUF = 3;
+  extern __shared__ __align__(16) double smem[];
+  const int H = S >> 1, LDA = H + 2;
+  double* As_e = smem;                      // [TJ][LDA] resident half-basis slices
+  double* As_o = As_e + TJ * LDA;           // [TJ][LDA]
+  double* Bs = As_o + TJ * LDA;             // [NBUF buffers][2 parities][TR][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int jw = (wave >> 1) * 16, rw = (wave & 1) * 16;
+  const int j0 = blockIdx.y * TJ, r0 = blockIdx.x * TR;
+  for (int i = tid; i < TJ * (H / 2); i += 256) {
+    const int row = i / (H / 2), c2 = (i % (H / 2)) * 2;
+    const double2 ve = *reinterpret_cast<const double2*>(Ah + (int64_t)(j0 + row) * H + c2);
+    const double2 vo = *reinterpret_cast<const double2*>(Ah + (int64_t)H * H + (int64_t)(j0 + row) * H + c2);
+    *reinterpret_cast<double2*>(&As_e[row * LDA + c2]) = ve;
+    *reinterpret_cast<double2*>(&As_o[row * LDA + c2]) = vo;
+  }
+  const int srow = tid >> 3, sq = tid & 7;  // staging: row of the r tile, 8-double piece of the 64 doubles per row and chunk
+  const int nkc = H / BK;
+  // planes of this workgroup: p = blockIdx.z, + gridDim.z, ...  (finished images of a CG batch are skipped)
+  int pl[8], npl = 0;
+  for (int p = blockIdx.z; p < planes && npl < 8; p += gridDim.z)
+    if (states == nullptr || states[p / 3].done == 0) pl[npl++] = p;
+  const int total = npl * nkc;
+  if (total == 0) return;
+  // Chunk t + 2 is fetched into registers while chunk t is multiplied and chunk t + 1 waits in LDS (three LDS buffers, two
+  // register sets): with one workgroup per CU the memory latency of a chunk is otherwise exposed every 32 K steps.
+  double ra[2][8];
+  auto load_chunk = [&](int t, int set) {
+    const double* row = X + (int64_t)pl[t / nkc] * S * S + (int64_t)(r0 + srow) * S;
+    const int n0 = (t % nkc) * BK;
+    if (INV) {  // (even, odd) sample pairs j = n0 + 8 e + sq: the 8 lanes of a row read 128 contiguous bytes per load
+      const double2* p2 = reinterpret_cast<const double2*>(row + 2 * n0) + sq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double2 v = p2[8 * e];
+        ra[set][2 * e] = v.x, ra[set][2 * e + 1] = v.y;
+      }
+    } else {    // 4 samples at n0 + 4 sq and their mirror images S - 1 - n
+      const double2* lo = reinterpret_cast<const double2*>(row + n0 + 4 * sq);
+      const double2* hi = reinterpret_cast<const double2*>(row + S - BK - n0 + 28 - 4 * sq);
+      const double2 l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
+      ra[set][0] = l0.x, ra[set][1] = l0.y, ra[set][2] = l1.x, ra[set][3] = l1.y;
+      ra[set][4] = h1.y, ra[set][5] = h1.x, ra[set][6] = h0.y, ra[set][7] = h0.x;  // mirrors of samples 0 .. 3
+    }
+  };
+  auto store_chunk = [&](int buf, int set) {
+    double* b0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + 4 * sq;
+    double* b1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + 4 * sq;
+    if (INV) {  // pair j = 8 e + sq of the chunk: even sample to parity 0, odd sample to parity 1
+      double* c0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + sq;
+      double* c1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + sq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c0[8 * e] = ra[set][2 * e], c1[8 * e] = ra[set][2 * e + 1];
+    } else {
+      *reinterpret_cast<double2*>(b0) = make_double2(ra[set][0] + ra[set][4], ra[set][1] + ra[set][5]);
+      *reinterpret_cast<double2*>(b0 + 2) = make_double2(ra[set][2] + ra[set][6], ra[set][3] + ra[set][7]);
+      *reinterpret_cast<double2*>(b1) = make_double2(ra[set][0] - ra[set][4], ra[set][1] - ra[set][5]);
+      *reinterpret_cast<double2*>(b1 + 2) = make_double2(ra[set][2] - ra[set][6], ra[set][3] - ra[set][7]);
+    }
+  };
+  load_chunk(0, 0);
+  if (total > 1) load_chunk(1, 1);
+  store_chunk(0, 0);
+  __syncthreads();
+  double4_t acc_e = {0.0, 0.0, 0.0, 0.0}, acc_o = {0.0, 0.0, 0.0, 0.0};
+  // unrolled by two so that the register sets are addressed statically: even t uses set 0 for chunk t + 2, odd t set 1
+  auto step = [&](int t, int set_next, int set_far) {
+    const int buf = t % NBUF;
+    // chunk t + 1 (already in registers, set_next) goes to LDS buffer (t + 1) % NBUF; chunk t + 2 is requested into set_far
+    if (t + 1 < total) store_chunk((t + 1) % NBUF, set_next);
+    if (t + 2 < total) load_chunk(t + 2, set_far);
+    const int kc = t % nkc;
+    const double* be = Bs + (buf * 2 + 0) * TR * LDB + (rw + li) * LDB + lk;
+    const double* bo = Bs + (buf * 2 + 1) * TR * LDB + (rw + li) * LDB + lk;
+    const double* ae = As_e + (jw + li) * LDA + kc * BK + lk;
+    const double* ao = As_o + (jw + li) * LDA + kc * BK + lk;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      acc_e = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[kk], be[kk], acc_e, 0, 0, 0);
+      acc_o = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[kk], bo[kk], acc_o, 0, 0, 0);
+    }
+    if (kc == nkc - 1) {  // a plane is complete: write its two output row families
+      double* Cp = C + (int64_t)pl[t / nkc] * S * S;
+      const double* Ap = add != nullptr ? add + (int64_t)pl[t / nkc] * S * S : nullptr;
+      const int col = r0 + rw + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jj = j0 + jw + lk + 4 * q;
+        int64_t o0, o1;
+        double v0, v1;
+        if (INV) {
+          o0 = (int64_t)jj * S + col, o1 = (int64_t)(S - 1 - jj) * S + col;
+          v0 = acc_e[q] + acc_o[q], v1 = acc_e[q] - acc_o[q];
+        } else {
+          o0 = (int64_t)(2 * jj) * S + col, o1 = o0 + S;
+          v0 = acc_e[q], v1 = acc_o[q];
+        }
+        Cp[o0] = Ap != nullptr ? fma(add_scale, Ap[o0], v0) : v0;
+        Cp[o1] = Ap != nullptr ? fma(add_scale, Ap[o1], v1) : v1;
+      }
+      acc_e = double4_t{0.0, 0.0, 0.0, 0.0};
+      acc_o = double4_t{0.0, 0.0, 0.0, 0.0};
+    }
+    __syncthreads();  // chunk t + 1 is visible; buffer (t + 2) % NBUF - read two steps ago - is free for the next store
+  };
+  for (int t = 0; t < total; t += 2) {
+    step(t, 1, 0);
+    if (t + 1 < total) step(t + 1, 0, 1);
+  }
+}
+
 // Two dense S x S passes over `planes` images: T = X b_w^T (along W), out = b_h T (along H) [+ add_scale * add].
 // b_w = b_h = the DCT basis (or its transpose) gives the 2-D DCT-II / DCT-III; a separable blur folded into the bases
 // (fh_problem.fold_*) makes the same two passes compute dct2(A^T x) or A(idct2(x)).
 static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, int planes, const double* b_w, const double* b_h,
                               const double* add, double add_scale, const fh_cg_state* states, hipStream_t st);
 
+// the two symmetric passes: tmp = (X P_w^T)^T, out = P_h X P_w^T (+ add_scale * add); sym_* = packed half bases [2][S/2][S/2]
+static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int planes, const double* sym_w,
+                            const double* sym_h, int inverse, const double* add, double add_scale,
+                            const fh_cg_state* states, hipStream_t st) {
+  const int S = ctx->S, H = S / 2;
+  if (planes > ctx->planes_max || S % 64 != 0) return FH_ESIZE;
+  const int gx = S / 32, gy = H / 32;
+  int gz = 256 / (gx * gy);
+  if (gz < (planes + 7) / 8) gz = (planes + 7) / 8;
+  if (gz > planes) gz = planes;
+  if (gz < 1) gz = 1;
+  const size_t lds = ((size_t)2 * 32 * (H + 2) + (size_t)3 * 2 * 32 * 34) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dct_sym<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 140 * 1024));
+    FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dct_sym<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 140 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid(gx, gy, gz);
+  if (inverse) {
+    hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
+                       (const double*)nullptr, 0.0);
+    hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
+                       add, add_scale);
+  } else {
+    hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
+                       (const double*)nullptr, 0.0);
+    hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
+                       add, add_scale);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
 static int dct2d_launch(fh_context* ctx, const double* in, double* out, int planes, int inverse,
                         const fh_cg_state* states, hipStream_t st) {
+  static const bool no_sym = getenv("FH_DCT_NOSYM") != nullptr;  // A/B switch: the dense passes
+  if (ctx->sym_fwd != nullptr && !no_sym) {
+    const double* sb = inverse ? ctx->sym_inv : ctx->sym_fwd;
+    return dct2d_launch_sym(ctx, in, out, planes, sb, sb, inverse, nullptr, 0.0, states, st);
+  }
   const double* b1 = inverse ? ctx->basis_t : ctx->basis;
   return dct2d_launch_bases(ctx, in, out, planes, b1, b1, nullptr, 0.0, states, st);
 }
@@ -1372,6 +1543,13 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per,
     // separable blur folded into the DCT bases: out = sigma_y^2 u + A idct2( C dct2(A^T u) ) in 4 dense passes + the
     // apply, instead of 4 blur passes + 4 DCT passes + the apply + an axpy epilogue
     if (!p->fold_fwd_h || !p->fold_inv_w || !p->fold_inv_h) return FH_EINVAL;
+    if (p->fold_sym) {  // symmetric PSF: the fold pointers are packed half bases (k_dct_sym)
+      rc = dct2d_launch_sym(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, 0, nullptr, 0.0, states, st);
+      if (rc) return rc;
+      rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
+      if (rc) return rc;
+      return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st);
+    }
     rc = dct2d_launch_bases(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, nullptr, 0.0, states, st);
     if (rc) return rc;
     rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
@@ -1612,6 +1790,21 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->basis_t, sizeof(double) * S * S));
   FH_CHECK(hipMemcpy(c->basis, bas.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
   FH_CHECK(hipMemcpy(c->basis_t, bast.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
+  if (S % 64 == 0) {  // packed half bases of the symmetric passes: forward [Pe; Po], inverse [Qe; Qo] (k_dct_sym)
+    const int H = S / 2;
+    std::vector<double> sf((size_t)2 * H * H), si((size_t)2 * H * H);
+    for (int j = 0; j < H; ++j)
+      for (int n = 0; n < H; ++n) {
+        sf[(size_t)j * H + n] = bas[(size_t)(2 * j) * S + n];                      // Pe[j][n] = C[2j][n]
+        sf[(size_t)H * H + (size_t)j * H + n] = bas[(size_t)(2 * j + 1) * S + n];  // Po[j][n] = C[2j+1][n]
+        si[(size_t)j * H + n] = bas[(size_t)(2 * n) * S + j];                      // Qe[k][j'] = C[2j'][k]  (here k = j, j' = n)
+        si[(size_t)H * H + (size_t)j * H + n] = bas[(size_t)(2 * n + 1) * S + j];  // Qo[k][j'] = C[2j'+1][k]
+      }
+    FH_CHECK(hipMalloc(&c->sym_fwd, sizeof(double) * 2 * H * H));
+    FH_CHECK(hipMalloc(&c->sym_inv, sizeof(double) * 2 * H * H));
+    FH_CHECK(hipMemcpy(c->sym_fwd, sf.data(), sizeof(double) * 2 * H * H, hipMemcpyHostToDevice));
+    FH_CHECK(hipMemcpy(c->sym_inv, si.data(), sizeof(double) * 2 * H * H, hipMemcpyHostToDevice));
+  }
   FH_CHECK(hipMalloc(&c->tmp_img, sizeof(double) * nimg));
   FH_CHECK(hipMalloc(&c->partial, sizeof(double) * kPartialRows * FH_MAX_COLS * c->nimg_max));
   FH_CHECK(hipMalloc(&c->gpartial, sizeof(double) * c->gpartial_elems));
@@ -1643,7 +1836,8 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
 int fh_context_destroy(fh_context* c) {
   if (c == nullptr) return 0;
   void* bufs[] = {c->basis, c->basis_t, c->tmp_img, c->partial, c->gpartial, c->coef, c->cg_r,
-                  c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state, c->sync};
+                  c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state, c->sync,
+                  c->sym_fwd, c->sym_inv};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& g : c->graphs)

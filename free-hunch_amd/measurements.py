@@ -110,6 +110,23 @@ def folded_dct_blur_bases(col_dy, col_w, row_dx, row_w, S):
     return f(P_row), f(P_col), f(P_row.T), f(P_col.T)
 
 
+def pack_symmetric_halves(P):
+    """If the S x S basis P has the DCT's mirror symmetry P[k][S-1-n] = (-1)^k P[k][n] (the DCT itself; a SYMMETRIC blur
+    folded into it), return the packed half bases of fh_problem.fold_sym = 1 (include/fh_hip.h): forward [Pe; Po] with
+    Pe[j][n] = P[2j][n], Po[j][n] = P[2j+1][n], and inverse [Qe; Qo] = [Pe^T; Po^T], each float64 [2][S/2][S/2]; else None."""
+    S = P.shape[0]
+    if S % 64 != 0:
+        return None
+    H = S // 2
+    sign = np.where(np.arange(S) % 2 == 0, 1.0, -1.0)[:, None]
+    if np.abs(P[:, ::-1] * sign - P).max() > 1e-13 * np.abs(P).max():
+        return None
+    Pe, Po = P[0::2, :H], P[1::2, :H]
+    fwd = np.ascontiguousarray(np.stack([Pe, Po]))
+    inv = np.ascontiguousarray(np.stack([Pe.T, Po.T]))
+    return fwd, inv
+
+
 _FOLD_CACHE = {}
 
 
@@ -139,8 +156,8 @@ class LinearOperator:
         return out
 
     def folded_bases(self):
-        """Device copies of `folded_dct_blur_bases` for this operator's separable PSF (None when the PSF is not rank-1 or
-        the operator decimates); built once per (PSF, size, device) and shared by all operator instances."""
+        """(device copies of `folded_dct_blur_bases` for this operator's separable PSF, packed-symmetric flag) - None when
+        the PSF is not rank-1 or the operator decimates; built once per (PSF, size, device), shared by all instances."""
         sep = getattr(getattr(self, "taps", None), "sep", None)
         if sep is None or self.name == "super_resolution" or os.environ.get("FH_NO_FOLD") == "1":
             return None
@@ -151,7 +168,11 @@ class LinearOperator:
         if key not in _FOLD_CACHE:
             mats = folded_dct_blur_bases(col.dy.cpu().numpy(), col.w.cpu().numpy(), row.dx.cpu().numpy(),
                                          row.w.cpu().numpy(), S)
-            _FOLD_CACHE[key] = tuple(torch.from_numpy(m).to(self.device) for m in mats)
+            hw, hh = pack_symmetric_halves(mats[0]), pack_symmetric_halves(mats[1])
+            sym = hw is not None and hh is not None and os.environ.get("FH_DCT_NOSYM") is None
+            if sym:  # (fold_fwd_w, fold_fwd_h, fold_inv_w, fold_inv_h) as packed halves
+                mats = (hw[0], hh[0], hw[1], hh[1])
+            _FOLD_CACHE[key] = (tuple(torch.from_numpy(m).to(self.device) for m in mats), sym)
         return _FOLD_CACHE[key]
 
     def _noise(self, y, noiseless):

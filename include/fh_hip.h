@@ -188,7 +188,10 @@ typedef struct fh_problem {
    * variants call it (x0 = 0, the initial residual is tested first - tol >= 1 returns 0 without iterating - and no pAp
    * test; conditioning_mechanisms.py:379, 444, 474, 548, 630, 696). */
   int32_t cg_scipy;
-  int32_t reserved0;
+  /* 1: the four fold_* pointers below are PACKED HALF bases [2][S/2][S/2] of a basis with the DCT's mirror symmetry
+   * P[k][S-1-n] = (-1)^k P[k][n] (a symmetric PSF): forward [Pe; Po] with Pe[j][n] = P[2j][n], Po[j][n] = P[2j+1][n];
+   * inverse [Qe; Qo] with Qe[k][j] = P[2j][k], Qo[k][j] = P[2j+1][k] (k, n, j < S/2) - half the multiply-adds (k_dct_sym). */
+  int32_t fold_sym;
   const int32_t* tap2_dy;
   const int32_t* tap2_dx;
   const double* tap2_w;

@@ -172,7 +172,7 @@ def test_folded_blur_dct_equals_tap_passes(dev, S, monkeypatch):
     """A_mm(u) = sigma_y^2 u + A idct2(C dct2(A^T u)) for the Gaussian blur with the DCT prior: the path that folds the two
     1-D blur passes into the DCT bases (4 dense passes + apply) against the tap-list path (4 blur passes + 4 DCT passes +
     apply).  Same linear map, different rounding: 1e-12 of max|out|.  Also the whole solve: same iteration count and
-    solution to 1e-9 at a tight tolerance."""
+    solution to 1e-8 at rtol = 1e-8."""
     import ctypes as C
     from free_hunch_amd import _lib, covariance as hc
     from free_hunch_amd.conditioning_mechanisms import _problem, _sigma_y2, solve_customcuda
@@ -210,7 +210,7 @@ def test_folded_blur_dct_equals_tap_passes(dev, S, monkeypatch):
         sols.append(solve_customcuda(op, y, x0, cov, 1.0, 0.3, info, rtol=1e-8))
         infos.append(info[0])
     assert infos[0]["niter"] == infos[1]["niter"] and infos[0]["optimal"]
-    assert maxabs(sols[0], sols[1]) < 1e-9 * float(sols[1].abs().max())
+    assert maxabs(sols[0], sols[1]) < 1e-8 * float(sols[1].abs().max())  # two rtol = 1e-8 solves of the same system
 
 
 # ---------------------------------------------------------------- a11-a12 at 256 x 256
