@@ -321,8 +321,10 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self._rec = dict(info[0])
         return mat
 
-    def fh_update(self, x_det, m_det, sigma, model=None):
-        """the covariance part of a guidance call: time update (sigma changed) and space update (x changed)"""
+    def fh_update(self, x_det, m_det, sigma, model=None, x_changed=None):
+        """the covariance part of a guidance call: time update (sigma changed) and space update (x changed).
+        `x_changed`: the result of `not torch.allclose(x, x_prev)` (:250) when the caller has already evaluated it (the
+        lock-step sampler does so for the whole batch with one device -> host transfer)."""
         cm = self.covariance_model
         s = float(sigma)
         if self.do_space_updates:
@@ -332,7 +334,7 @@ class BFGSOnlineUpdate(ConditioningMechanism):
                 pred, _ = cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous)
             elif len(self.sigmas) != 0:  # second Heun evaluation at the same sigma: no time update
                 pred = self.denoiser_means[-1]
-            if len(self.xs) != 0 and not torch.allclose(x_det, self.xs[-1]):
+            if len(self.xs) != 0 and (x_changed if x_changed is not None else not torch.allclose(x_det, self.xs[-1])):
                 if not self.use_analytical_score_time_update:
                     with torch.no_grad():
                         pred, _ = model(self.xs[-1], sigma)
@@ -342,20 +344,27 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             score_previous = (self.denoiser_means[-1] - self.xs[-1]) / self.sigmas[-1] ** 2
             cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous, only_covariance=True)
 
-    def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma, std=None):
+    def fh_branch(self, p_y_xt_grad, sigma, std=None):
+        """"cov" when the VJP guidance is judged unreliable (std(vjp * sigma^2) > threshold, :283), else "vjp" """
+        if self._rec.get("analytic"):  # :277-278: always the VJP form
+            return "vjp"
+        if std is None:
+            std = (p_y_xt_grad * torch.as_tensor(sigma, dtype=F64, device=p_y_xt_grad.device).pow(2)).std()
+        return "cov" if std > self.denoiser_mean_error_threshold else "vjp"
+
+    def fh_finish(self, mat, p_y_xt_grad, x_det, m_det, sigma, std=None, cov_mat=None):
         """`std`: (p_y_xt_grad * sigma^2).std() when the caller has already reduced it (the lock-step sampler does it for
-        the whole batch with one device -> host transfer instead of one per image)."""
+        the whole batch with one device -> host transfer instead of one per image); `cov_mat`: C . mat when the caller has
+        already applied the covariance (for the whole batch in one kernel sequence)."""
         cm, rec, s = self.covariance_model, self._rec, float(sigma)
         sig2 = torch.as_tensor(sigma, dtype=F64, device=m_det.device).pow(2)
-        if rec.get("analytic"):  # :277-278: always the VJP form
+        if self.fh_branch(p_y_xt_grad, sigma, std) == "vjp":
             p_y_xt_grad = p_y_xt_grad * self.cond_scaling
             rec["branch"] = "vjp"
-        elif (std if std is not None else (p_y_xt_grad * sig2).std()) > self.denoiser_mean_error_threshold:
-            p_y_xt_grad = cm.denoiser_cov_vector_dot(mat.detach(), use_cuda=True) * self.cond_scaling / sig2
-            rec["branch"] = "cov"
         else:
-            p_y_xt_grad = p_y_xt_grad * self.cond_scaling
-            rec["branch"] = "vjp"
+            cv = cov_mat if cov_mat is not None else cm.denoiser_cov_vector_dot(mat.detach(), use_cuda=True)
+            p_y_xt_grad = cv * self.cond_scaling / sig2
+            rec["branch"] = "cov"
         x_0_mean_new = m_det + p_y_xt_grad * sig2
         rec["k"], rec["sigma"] = cm.k, s
         if os.environ.get("FH_TRACE_SUMS"):  # debugging aid: costs a device sync per call

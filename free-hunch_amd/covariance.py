@@ -258,6 +258,31 @@ class CovarianceHessianBFGS:
         out = self._apply(self.C, self.famC, z, torch.empty_like(z))
         return self._bwd(out).reshape(shape).to(dtype)
 
+    @staticmethod
+    def denoiser_cov_vector_dot_batched(models, v, slot=0):
+        """`denoiser_cov_vector_dot` of B covariance objects (same basis, same number of factor columns - a lock-step batch)
+        on the B rows of v [B,3,S,S] in ONE kernel sequence: batched DCT (3B planes), fh_rep_apply_batched, batched IDCT.
+        Same arithmetic per image as the per-object method (the batched kernels are bitwise equal to the single ones)."""
+        m0 = models[0]
+        B, S, d = len(models), m0.S, m0.data_dim
+        assert v.shape[0] == B and all(mm.famC.m == m0.famC.m and mm.use_dct == m0.use_dct for mm in models)
+        ctx = _lib.Context.get(S, 3 * B, 0, slot=7000 + 64 * slot + B)
+        shape, dtype = v.shape, v.dtype
+        z = v.detach().to(device=m0.device, dtype=F64).contiguous()
+        if m0.use_dct:
+            z = ctx.dct2d(z.view(3 * B, S, S))
+        per = _lib.FhBatch()
+        per.nimg = B
+        for b, mm in enumerate(models):
+            per.D[b], per.r[b], per.B[b], per.M[b] = (mm.C.D.data_ptr(), mm.C.r.data_ptr(), mm.famC.B.data_ptr(),
+                                                      mm.C.M_dev.data_ptr())
+        out = torch.empty_like(z)
+        _lib.check(ctx.lib.fh_rep_apply_batched(ctx.h, C.byref(per), m0.C.M_dev.shape[1], z.data_ptr(), out.data_ptr(), d,
+                                                m0.famC.m, _lib.stream()), "fh_rep_apply_batched")
+        if m0.use_dct:
+            out = ctx.dct2d(out.view(3 * B, S, S), inverse=True)
+        return out.reshape(shape).to(dtype)
+
     # ------------------------------------------------------------------ :153-192
     def update_time_step(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance=False):
         shape = x_t.shape

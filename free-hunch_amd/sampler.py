@@ -197,8 +197,15 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
         t0 = _tick("fwd", t0)
         x_det, m_det = x_t.detach(), x0_mean.detach()
         if batched_cg and not mechs[0].analytic_now(sigma):
-            # covariance updates per image on their own streams, then ONE kernel sequence solves all B systems
-            fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net), x_det[b:b + 1])[1])
+            # covariance updates per image on their own streams, then ONE kernel sequence solves all B systems.
+            # `not torch.allclose(x, x_prev)` (:250) of all images with one device -> host transfer
+            changed = [None] * B
+            if all(len(mm.xs) != 0 for mm in mechs):
+                prev = torch.cat([mm.xs[-1] for mm in mechs], 0)
+                close = ((x_det - prev).abs() <= 1e-8 + 1e-5 * prev.abs()).reshape(B, -1).all(dim=1)  # allclose's rule
+                changed = [not c for c in close.tolist()]
+            fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net, x_changed=changed[b]),
+                               x_det[b:b + 1])[1])
             t0 = _tick("update", t0)
             infos = []
             mats = solve_customcuda_batched(operators, ys, [m_det[b:b + 1] for b in range(B)],
@@ -213,8 +220,21 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
         t0 = _tick("vjp", t0)
         # the 0.2-std branch statistic (conditioning_mechanisms.py:283) of all images with one device -> host transfer
         stds = (g * sigma.pow(2)).reshape(B, -1).std(dim=1).tolist()
-        outs = fan_out(lambda b: mechs[b].fh_finish(mats[b:b + 1], g[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], sigma,
-                                                    std=stds[b]))
+        # images on the "cov" branch get C . mat from ONE batched kernel sequence (batched DCT, apply, IDCT) when the whole
+        # batch shares the factor count; the per-image finish is then host bookkeeping + two elementwise ops, no fan-out
+        cov_all = None
+        is_fh = hasattr(mechs[0], "covariance_model")
+        need_cov = [is_fh and mechs[b].fh_branch(None, sigma, stds[b]) == "cov" for b in range(B)]
+        if any(need_cov) and len({mm.covariance_model.famC.m for mm in mechs}) == 1:
+            from .covariance import CovarianceHessianBFGS
+            cov_all = CovarianceHessianBFGS.denoiser_cov_vector_dot_batched([mm.covariance_model for mm in mechs], mats.detach(),
+                                                                            slot=slot_base)
+        if cov_all is not None or not any(need_cov):
+            outs = [mechs[b].fh_finish(mats[b:b + 1], g[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], sigma, std=stds[b],
+                                       cov_mat=cov_all[b:b + 1] if need_cov[b] else None) for b in range(B)]
+        else:
+            outs = fan_out(lambda b: mechs[b].fh_finish(mats[b:b + 1], g[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], sigma,
+                                                        std=stds[b]))
         out = torch.cat(outs, 0)
         _tick("finish", t0)
         return out.clip(-1, 1) if o["clip_x0_mean"] else out
