@@ -288,16 +288,17 @@ def host_cpu_info():
 def cpu_baseline(arch, operator_name, num_steps, data_dir, unet_calls=2, solver="heun"):
     """The oracle (a port of the reference path, pinned to the reference by tests/test_oracle_golden.py) on the host cores,
     on a bounded sample of the bench workload (one full image is ~7 min of CPU time, beyond the bench budget):
-      * the Free Hunch side of ALL 2 N - 1 guidance calls of one 256 x 256 image - time / space updates, the CG solve through
-        the operator, the 0.2-std branch - so every sigma from 80 to 0.01 and every factor count k = 0 .. 16 is sampled, with
-        a closed-form Gaussian-prior denoiser standing in for the UNet (the FH side's cost depends on sigma and k, not on
-        where the denoiser values come from);
+      * the Free Hunch side - time / space updates, the CG solve through the operator, the 0.2-std branch - of every guidance
+        call of a 10-step trajectory of one 256 x 256 image (same sigma range 80 -> 0.01, space updates included), scaled by
+        the call count, with a closed-form Gaussian-prior denoiser standing in for the UNet (the FH side's cost depends on
+        sigma and k, not on where the denoiser values come from);
       * the UNet forward + input-VJP of the named architecture, timed on `unet_calls` real calls (its cost does not depend on
         sigma), and one call of the ImageNet-256 architecture for BASELINE configs[0];
     images/s = 1 / (FH side + (2 N - 1) x UNet call)."""
     from oracle import fh_oracle as fo, unet_oracle as uo
     model, phys, logical = host_cpu_info()
-    threads = max(1, min(phys, 64))
+    threads = max(1, min(phys, 64))       # UNet convolutions scale to the cores
+    fh_threads = max(1, min(phys, 32))    # the FH side (256^2 FFTs / DCTs, [d, k] products) is fastest at <= 32 threads
     torch.set_num_threads(threads)
     S = 256
     kd = os.path.join(ROOT, "free-hunch_amd", "data", "kernels")
@@ -345,17 +346,26 @@ def cpu_baseline(arch, operator_name, num_steps, data_dir, unet_calls=2, solver=
                 return out
         return Timed()
 
+    # bounded sample: a Heun-10 trajectory (19 guidance calls over the same sigma range 80 -> 0.01, space updates included)
+    # stands for the 59 calls of Heun-30 - per-call cost is a function of sigma (CG tolerance) and k - and is scaled by the
+    # call count; k only reaches 5 instead of 16 here, which favours the CPU slightly
+    sample_steps = min(num_steps, 10)
+    torch.set_num_threads(fh_threads)
     t0 = time.perf_counter()
-    fo.conditional_sampler(StandIn(), noise, y, op, num_steps=num_steps, solver=solver, mechanism_factory=fac)
+    fo.conditional_sampler(StandIn(), noise, y, op, num_steps=sample_steps, solver=solver, mechanism_factory=fac)
     wall_fh = time.perf_counter() - t0
-    t_fh = float(np.sum(fh_times))
+    torch.set_num_threads(threads)
+    t_fh = float(np.sum(fh_times)) * n_calls / len(fh_times)
     per_image = t_fh + n_calls * t_unet
     out = {"value": round(1.0 / per_image, 6), "unit": "images/s", "cores": threads, "kind": "port",
            "host_cpu": model, "physical_cores": phys, "logical_cpus": logical,
-           "sample": f"Free Hunch side of all {len(fh_times)} guidance calls of one image ({t_fh:.1f} s: sigma 80 -> 0.01, "
-                     f"k 0 -> 16, {int(np.sum(iters))} CG iterations; closed-form stand-in denoiser) + {unet_calls} timed "
-                     f"{arch.upper()}-256 UNet forward+VJP calls ({t_unet:.2f} s each) x {n_calls}; "
-                     f"{per_image:.0f} s per image, {wall_fh + unet_calls * t_unet:.0f} s of CPU work sampled"}
+           "fh_side_threads": fh_threads,
+           "sample": f"Free Hunch side of the {len(fh_times)} guidance calls of a {solver}-{sample_steps} trajectory of one "
+                     f"256x256 image ({float(np.sum(fh_times)):.1f} s on {fh_threads} threads: sigma 80 -> 0.01, "
+                     f"{int(np.sum(iters))} CG iterations; closed-form stand-in denoiser), scaled to {n_calls} calls "
+                     f"({t_fh:.0f} s) + {unet_calls} timed {arch.upper()}-256 UNet forward+VJP calls ({t_unet:.2f} s each on "
+                     f"{threads} threads) x {n_calls}; {per_image:.0f} s per image, "
+                     f"{wall_fh + unet_calls * t_unet:.0f} s of CPU work sampled"}
     if arch != "imagenet":  # BASELINE configs[0]: the ImageNet-256 architecture on the CPU path, one timed UNet call
         t_im, _ = unet_call_seconds(uo.IMAGENET256, 1)
         out["imagenet256_arch"] = {"value": round(1.0 / (t_fh + n_calls * t_im), 6), "unit": "images/s",
