@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
                                                  double* __restrict__ C, int S, int planes,
                                                  const fh_cg_state* __restrict__ states, const double* __restrict__ add,
                                                  double add_scale) {
-  constexpr int TJ = 32, TR = 32, BK = 32, LDB = BK + 2, NBUF = 3;
+  // K chunks of 64 (two per plane at S = 256): the per-chunk cost besides the 16 MFMA pairs - LDS stores, the barrier, the
+  // wait for the prefetched rows - was ~65 % of a 32-wide chunk's time (measured 14.4 us per pass at BK = 32, 36 % of the f64
+  // MFMA rate); halving the chunk count halves it.  Two LDS buffers, the next chunk prefetched into registers.
+  constexpr int TJ = 32, TR = 32, BK = 64, LDB = BK + 2, NBUF = 2, NP8 = BK / 32;  // NP8 pieces of 8 doubles per thread
   extern __shared__ __align__(16) double smem[];
   const int H = S >> 1, LDA = H + 2;
   double* As_e = smem;                      // [TJ][LDA] resident half-basis slices
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
     *reinterpret_cast<double2*>(&As_e[row * LDA + c2]) = ve;
     *reinterpret_cast<double2*>(&As_o[row * LDA + c2]) = vo;
   }
-  const int srow = tid >> 3, sq = tid & 7;  // staging: row of the r tile, 8-double piece of the 64 doubles per row and chunk
+  const int srow = tid >> 3, sq = tid & 7;  // staging: row of the r tile, lane within the row's 8-thread group
   const int nkc = H / BK;
   // planes of this workgroup: p = blockIdx.z, + gridDim.z, ...  (finished images of a CG batch are skipped)
   int pl[8], npl = 0;
@@ -204,53 +207,55 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
     if (states == nullptr || states[p / 3].done == 0) pl[npl++] = p;
   const int total = npl * nkc;
   if (total == 0) return;
-  // Chunk t + 2 is fetched into registers while chunk t is multiplied and chunk t + 1 waits in LDS (three LDS buffers, two
-  // register sets): with one workgroup per CU the memory latency of a chunk is otherwise exposed every 32 K steps.
-  double ra[2][8];
-  auto load_chunk = [&](int t, int set) {
+  double ra[NP8][8];
+  auto load_chunk = [&](int t) {
     const double* row = X + (int64_t)pl[t / nkc] * S * S + (int64_t)(r0 + srow) * S;
     const int n0 = (t % nkc) * BK;
-    if (INV) {  // (even, odd) sample pairs j = n0 + 8 e + sq: the 8 lanes of a row read 128 contiguous bytes per load
-      const double2* p2 = reinterpret_cast<const double2*>(row + 2 * n0) + sq;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double2 v = p2[8 * e];
-        ra[set][2 * e] = v.x, ra[set][2 * e + 1] = v.y;
+    for (int h = 0; h < NP8; ++h) {
+      if (INV) {  // (even, odd) sample pairs j = n0 + 32 h + 8 e + sq: 8 lanes of a row read 128 contiguous bytes per load
+        const double2* p2 = reinterpret_cast<const double2*>(row + 2 * (n0 + 32 * h)) + sq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double2 v = p2[8 * e];
+          ra[h][2 * e] = v.x, ra[h][2 * e + 1] = v.y;
+        }
+      } else {    // 4 samples at n = n0 + 32 h + 4 sq + i and their mirror images S - 1 - n
+        const int nb = n0 + 32 * h + 4 * sq;
+        const double2* lo = reinterpret_cast<const double2*>(row + nb);
+        const double2* hi = reinterpret_cast<const double2*>(row + S - 4 - nb);
+        const double2 l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
+        ra[h][0] = l0.x, ra[h][1] = l0.y, ra[h][2] = l1.x, ra[h][3] = l1.y;
+        ra[h][4] = h1.y, ra[h][5] = h1.x, ra[h][6] = h0.y, ra[h][7] = h0.x;  // mirrors of samples 0 .. 3
       }
-    } else {    // 4 samples at n0 + 4 sq and their mirror images S - 1 - n
-      const double2* lo = reinterpret_cast<const double2*>(row + n0 + 4 * sq);
-      const double2* hi = reinterpret_cast<const double2*>(row + S - BK - n0 + 28 - 4 * sq);
-      const double2 l0 = lo[0], l1 = lo[1], h0 = hi[0], h1 = hi[1];
-      ra[set][0] = l0.x, ra[set][1] = l0.y, ra[set][2] = l1.x, ra[set][3] = l1.y;
-      ra[set][4] = h1.y, ra[set][5] = h1.x, ra[set][6] = h0.y, ra[set][7] = h0.x;  // mirrors of samples 0 .. 3
     }
   };
-  auto store_chunk = [&](int buf, int set) {
-    double* b0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + 4 * sq;
-    double* b1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + 4 * sq;
-    if (INV) {  // pair j = 8 e + sq of the chunk: even sample to parity 0, odd sample to parity 1
-      double* c0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + sq;
-      double* c1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + sq;
+  auto store_chunk = [&](int buf) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) c0[8 * e] = ra[set][2 * e], c1[8 * e] = ra[set][2 * e + 1];
-    } else {
-      *reinterpret_cast<double2*>(b0) = make_double2(ra[set][0] + ra[set][4], ra[set][1] + ra[set][5]);
-      *reinterpret_cast<double2*>(b0 + 2) = make_double2(ra[set][2] + ra[set][6], ra[set][3] + ra[set][7]);
-      *reinterpret_cast<double2*>(b1) = make_double2(ra[set][0] - ra[set][4], ra[set][1] - ra[set][5]);
-      *reinterpret_cast<double2*>(b1 + 2) = make_double2(ra[set][2] - ra[set][6], ra[set][3] - ra[set][7]);
+    for (int h = 0; h < NP8; ++h) {
+      if (INV) {  // pair j = 32 h + 8 e + sq of the chunk: even sample to parity 0, odd sample to parity 1
+        double* c0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + 32 * h + sq;
+        double* c1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + 32 * h + sq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c0[8 * e] = ra[h][2 * e], c1[8 * e] = ra[h][2 * e + 1];
+      } else {
+        double* b0 = Bs + (buf * 2 + 0) * TR * LDB + srow * LDB + 32 * h + 4 * sq;
+        double* b1 = Bs + (buf * 2 + 1) * TR * LDB + srow * LDB + 32 * h + 4 * sq;
+        *reinterpret_cast<double2*>(b0) = make_double2(ra[h][0] + ra[h][4], ra[h][1] + ra[h][5]);
+        *reinterpret_cast<double2*>(b0 + 2) = make_double2(ra[h][2] + ra[h][6], ra[h][3] + ra[h][7]);
+        *reinterpret_cast<double2*>(b1) = make_double2(ra[h][0] - ra[h][4], ra[h][1] - ra[h][5]);
+        *reinterpret_cast<double2*>(b1 + 2) = make_double2(ra[h][2] - ra[h][6], ra[h][3] - ra[h][7]);
+      }
     }
   };
-  load_chunk(0, 0);
-  if (total > 1) load_chunk(1, 1);
-  store_chunk(0, 0);
+  load_chunk(0);
+  store_chunk(0);
   __syncthreads();
   double4_t acc_e = {0.0, 0.0, 0.0, 0.0}, acc_o = {0.0, 0.0, 0.0, 0.0};
-  // unrolled by two so that the register sets are addressed statically: even t uses set 0 for chunk t + 2, odd t set 1
-  auto step = [&](int t, int set_next, int set_far) {
-    const int buf = t % NBUF;
-    // chunk t + 1 (already in registers, set_next) goes to LDS buffer (t + 1) % NBUF; chunk t + 2 is requested into set_far
-    if (t + 1 < total) store_chunk((t + 1) % NBUF, set_next);
-    if (t + 2 < total) load_chunk(t + 2, set_far);
+  int buf = 0;
+  for (int t = 0; t < total; ++t, buf ^= 1) {
+    const bool more = t + 1 < total;
+    if (more) load_chunk(t + 1);
     const int kc = t % nkc;
     const double* be = Bs + (buf * 2 + 0) * TR * LDB + (rw + li) * LDB + lk;
     const double* bo = Bs + (buf * 2 + 1) * TR * LDB + (rw + li) * LDB + lk;
@@ -283,11 +288,8 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
       acc_e = double4_t{0.0, 0.0, 0.0, 0.0};
       acc_o = double4_t{0.0, 0.0, 0.0, 0.0};
     }
-    __syncthreads();  // chunk t + 1 is visible; buffer (t + 2) % NBUF - read two steps ago - is free for the next store
-  };
-  for (int t = 0; t < total; t += 2) {
-    step(t, 1, 0);
-    if (t + 1 < total) step(t + 1, 0, 1);
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
   }
 }
 
@@ -302,13 +304,14 @@ static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int 
                             const double* sym_h, int inverse, const double* add, double add_scale,
                             const fh_cg_state* states, hipStream_t st) {
   const int S = ctx->S, H = S / 2;
-  if (planes > ctx->planes_max || S % 64 != 0) return FH_ESIZE;
+  if (planes > ctx->planes_max || S % 128 != 0) return FH_ESIZE;
   const int gx = S / 32, gy = H / 32;
   int gz = 256 / (gx * gy);
   if (gz < (planes + 7) / 8) gz = (planes + 7) / 8;
   if (gz > planes) gz = planes;
   if (gz < 1) gz = 1;
-  const size_t lds = ((size_t)2 * 32 * (H + 2) + (size_t)3 * 2 * 32 * 34) * sizeof(double);
+  if (H % 64 != 0) return FH_ESIZE;  // K chunks of 64
+  const size_t lds = ((size_t)2 * 32 * (H + 2) + (size_t)2 * 2 * 32 * 66) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dct_sym<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1790,7 +1793,7 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   FH_CHECK(hipMalloc(&c->basis_t, sizeof(double) * S * S));
   FH_CHECK(hipMemcpy(c->basis, bas.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
   FH_CHECK(hipMemcpy(c->basis_t, bast.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
-  if (S % 64 == 0) {  // packed half bases of the symmetric passes: forward [Pe; Po], inverse [Qe; Qo] (k_dct_sym)
+  if (S % 128 == 0) {  // packed half bases of the symmetric passes: forward [Pe; Po], inverse [Qe; Qo] (k_dct_sym)
     const int H = S / 2;
     std::vector<double> sf((size_t)2 * H * H), si((size_t)2 * H * H);
     for (int j = 0; j < H; ++j)

@@ -115,7 +115,7 @@ def pack_symmetric_halves(P):
     folded into it), return the packed half bases of fh_problem.fold_sym = 1 (include/fh_hip.h): forward [Pe; Po] with
     Pe[j][n] = P[2j][n], Po[j][n] = P[2j+1][n], and inverse [Qe; Qo] = [Pe^T; Po^T], each float64 [2][S/2][S/2]; else None."""
     S = P.shape[0]
-    if S % 64 != 0:
+    if S % 128 != 0:  # k_dct_sym works on K chunks of 64 of the half range
         return None
     H = S // 2
     sign = np.where(np.arange(S) % 2 == 0, 1.0, -1.0)[:, None]

@@ -122,3 +122,29 @@ def test_folded_dct_blur_bases_equal_blur_then_dct():
     assert np.abs(P_col @ x @ P_row.T - scipy.fft.dctn(blur(x, -1), type=2, norm="ortho")).max() < 1e-13
     assert np.abs(P_col_t @ x @ P_row - blur(scipy.fft.idctn(x, type=2, norm="ortho"), +1)).max() < 1e-13
     assert np.array_equal(P_row_t, P_row.T) and np.array_equal(P_col_t, P_col.T)
+
+
+def test_symmetric_half_bases_reproduce_the_dct_passes():
+    """`pack_symmetric_halves` + the two transposed passes of k_dct_sym in NumPy: forward = butterflies x_n +- x_{S-1-n} against
+    the even / odd half bases, inverse = even / odd samples and E +- O outputs; both equal SciPy's orthonormal DCT-II / III."""
+    import scipy.fft
+    from free_hunch_amd.measurements import dct_basis_longdouble, pack_symmetric_halves
+    S, H = 128, 64
+    C = dct_basis_longdouble(S).astype(np.float64)
+    fwd, inv = pack_symmetric_halves(C)
+    assert fwd.shape == (2, H, H) and inv.shape == (2, H, H)
+    assert pack_symmetric_halves(C + np.triu(np.ones((S, S)), 1) * 1e-6) is None  # not mirror-symmetric: dense passes
+    x = np.random.default_rng(3).standard_normal((S, S))
+
+    def sym_pass(Ah, X, INV):  # out[k][r] = sum_n P[k][n] X[r][n]
+        out = np.zeros((S, S))
+        if not INV:
+            s, d = X[:, :H] + X[:, ::-1][:, :H], X[:, :H] - X[:, ::-1][:, :H]
+            out[0::2], out[1::2] = Ah[0] @ s.T, Ah[1] @ d.T
+        else:
+            E, O = Ah[0] @ X[:, 0::2].T, Ah[1] @ X[:, 1::2].T
+            out[:H], out[::-1][:H] = E + O, E - O
+        return out
+
+    assert np.abs(sym_pass(fwd, sym_pass(fwd, x, False), False) - scipy.fft.dctn(x, type=2, norm="ortho")).max() < 1e-13
+    assert np.abs(sym_pass(inv, sym_pass(inv, x, True), True) - scipy.fft.idctn(x, type=2, norm="ortho")).max() < 1e-13
