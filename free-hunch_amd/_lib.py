@@ -190,8 +190,10 @@ class Context:
         return out
 
     def rep_invert(self, Dx, rx, B, shift, Dy, ry, G, m):
-        check(self.lib.fh_rep_invert(self.h, ptr(Dx), ptr(rx) if m else None, ptr(B) if m else None, float(shift),
-                                     ptr(Dy), ptr(ry) if m else None, ptr(G) if m else None,
+        # the row scales travel also for an empty factor: the closed-form C^-1 update of fh_cov_space_update relies on
+        # r_inverse = r / D from the first pair on
+        check(self.lib.fh_rep_invert(self.h, ptr(Dx), ptr(rx), ptr(B) if m else None, float(shift),
+                                     ptr(Dy), ptr(ry), ptr(G) if m else None,
                                      G.shape[1] if m else 0, Dx.numel(), m, stream()), "fh_rep_invert")
 
     def read_scalars(self, scal, k):

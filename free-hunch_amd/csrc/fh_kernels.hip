@@ -2079,7 +2079,13 @@ int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* m
   if ((rc = fh_axpby(1.0, mean_xn, -1.0, mean_x, de, st->d, stream))) return rc;
   if ((rc = cov_fwd(ctx, st, de, de, 0, stream))) return rc;
   if ((rc = fh_space_prep(ctx, de, s2, dx, de, st->scal, st->d, stream))) return rc;  // de <- s2 dm; scal[0] = dx.de
-  if ((rc = fh_rep_apply(ctx, st->D[0], st->r[0], st->Bc, st->M[0], st->ldm, dx, cdx, st->d, mc, stream))) return rc;
+  // two-pass apply also on an exclusive context: the single-sweep kernel keeps c = M t in registers, and the closed-form
+  // C^-1 below reads it from ctx->coef
+  const int fused_was = ctx->fused_disabled;
+  ctx->fused_disabled = 1;
+  rc = fh_rep_apply(ctx, st->D[0], st->r[0], st->Bc, st->M[0], st->ldm, dx, cdx, st->d, mc, stream);
+  ctx->fused_disabled = fused_was;
+  if (rc) return rc;
   if ((rc = fh_dot(ctx, cdx, dx, st->scal, 1, st->d, stream))) return rc;              // scal[1] = dx.(C dx)
   if (!st->project && mc > 0)  // c = M t of that apply (ctx->coef) is needed after the next dots pass overwrites it
     hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ctx->coef, st->G, mc);

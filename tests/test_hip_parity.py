@@ -87,32 +87,70 @@ def test_covariance_vs_oracle(dev, gold, tmp_path, ci):
     dv = T(gold("covariance")["dct_variance16"]) if S == 16 else T(gold("solver")["dct_variance64"])
     torch.save(dv, tmp_path / "dct_variance.pt")
     orc, hip = _mk_pair(meta, str(tmp_path), dev)
-    steps = inputs.script(900 + ci, meta["shape"], meta["n"], meta["sigma0"], meta["neg"])
-    probe = inputs.randn(meta["shape"], 950 + ci)
-    tol = 1e-8 if meta["n"] <= 6 else 1e-7  # 20 chained updates: conditioning of the inner matrices accumulates
+    hip.ctx.set_exclusive(ci % 2)
+    try:
+        steps = inputs.script(900 + ci, meta["shape"], meta["n"], meta["sigma0"], meta["neg"])
+        probe = inputs.randn(meta["shape"], 950 + ci)
+        tol = 1e-8 if meta["n"] <= 6 else 1e-7  # 20 chained updates: conditioning of the inner matrices accumulates
+        for si, (what, a) in enumerate(steps):
+            if what == "time":
+                mo, so = orc.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"], only_covariance=meta["only_cov"])
+                mh, sh = hip.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev),
+                                              only_covariance=meta["only_cov"])
+                sc = max(1.0, float(mo.abs().max()))
+                assert maxabs(mh, mo) < tol * sc, (si, "mean")
+                assert maxabs(sh, so) < tol * sc, (si, "score")
+            else:
+                if meta["only_cov"]:
+                    continue
+                orc.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
+                hip.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
+            assert hip.k == orc.k
+            if not meta["only_cov"] and not meta["kw"]:
+                # the inverse representations are state too (read by the step-wise / m > 64 / truncating paths): C (C^-1 z) = z and
+                # H (H^-1 z) = z in the transform domain, for an exclusive context as well (single-sweep apply inside the update)
+                zz = probe.to(dev).double().reshape(-1)
+                for rep_a, rep_b, fam in ((hip.C, hip.Ci, hip.famC), (hip.H, hip.Hi, hip.famH)):
+                    t_ = hip._apply(rep_b, fam, zz, torch.empty_like(zz))
+                    back = hip._apply(rep_a, fam, t_, torch.empty_like(zz))
+                    assert maxabs(back, zz) < 1e-7 * float(zz.abs().max()), (si, "inverse consistency", fam is hip.famC)
+            ro = orc.denoiser_cov_vector_dot(probe)
+            rh = hip.denoiser_cov_vector_dot(probe.to(dev))
+            assert maxabs(rh, ro) < tol * max(1.0, float(ro.abs().max())), (si, "apply")
+            if S == 4:
+                for nm, a_, b_ in zip("C Ci H Hi".split(), hip.get_dense_matrices(), orc.dense()):
+                    b_ = b_.real
+                    if not (meta["kind"] == "identity"):
+                        continue
+                    assert maxabs(a_, b_) < 1e-7 * max(1.0, float(b_.abs().max())), (si, nm)
+    finally:
+        hip.ctx.set_exclusive(0)
+
+
+def test_covariance_switches_between_fused_and_stepwise_updates(dev, gold, tmp_path, monkeypatch):
+    """The one-call updates (fh_cov_time_update / fh_cov_space_update: forward time shift, closed-form C^-1) and the
+    step-by-step path (Woodbury through the inverse representation; taken beyond 64 columns) share the four representations:
+    a state built by one must be a valid input of the other.  First 10 scripted steps fused, the rest step-wise, vs the oracle."""
+    meta = CASES[6]
+    torch.save(T(gold("solver")["dct_variance64"]), tmp_path / "dct_variance.pt")
+    orc, hip = _mk_pair(meta, str(tmp_path), dev)
+    steps = inputs.script(906, meta["shape"], meta["n"], meta["sigma0"], meta["neg"])
+    probe = inputs.randn(meta["shape"], 956)
     for si, (what, a) in enumerate(steps):
+        if si == 10:
+            monkeypatch.setenv("FH_COV_STEPWISE", "1")
         if what == "time":
-            mo, so = orc.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"], only_covariance=meta["only_cov"])
-            mh, sh = hip.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev),
-                                          only_covariance=meta["only_cov"])
+            mo, so = orc.update_time_step(a["x"], a["sigma"], a["sigma_next"], a["score"])
+            mh, sh = hip.update_time_step(a["x"].to(dev), a["sigma"], a["sigma_next"], a["score"].to(dev))
             sc = max(1.0, float(mo.abs().max()))
-            assert maxabs(mh, mo) < tol * sc, (si, "mean")
-            assert maxabs(sh, so) < tol * sc, (si, "score")
+            assert maxabs(mh, mo) < 1e-7 * sc and maxabs(sh, so) < 1e-7 * sc, si
         else:
-            if meta["only_cov"]:
-                continue
             orc.update_space_step(a["m0"], a["m1"], a["sigma"], a["x"], a["xn"])
             hip.update_space_step(a["m0"].to(dev), a["m1"].to(dev), a["sigma"], a["x"].to(dev), a["xn"].to(dev))
-        assert hip.k == orc.k
         ro = orc.denoiser_cov_vector_dot(probe)
-        rh = hip.denoiser_cov_vector_dot(probe.to(dev))
-        assert maxabs(rh, ro) < tol * max(1.0, float(ro.abs().max())), (si, "apply")
-        if S == 4:
-            for nm, a_, b_ in zip("C Ci H Hi".split(), hip.get_dense_matrices(), orc.dense()):
-                b_ = b_.real
-                if not (meta["kind"] == "identity"):
-                    continue
-                assert maxabs(a_, b_) < 1e-7 * max(1.0, float(b_.abs().max())), (si, nm)
+        assert maxabs(hip.denoiser_cov_vector_dot(probe.to(dev)), ro) < 1e-7 * max(1.0, float(ro.abs().max())), si
+    assert hip.k == orc.k and hip.k >= 8
+
 
 
 def test_covariance_vs_reference_golden(dev, gold, tmp_path):

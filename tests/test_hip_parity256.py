@@ -430,11 +430,18 @@ def test_free_running_sr256_with_reference_unet_arithmetic(dev, gold):
                                         ("super_resolution", "sr256_heun30"), ("inpainting", "ip256_heun30")])
 def test_teacher_forced_256(dev, gold, opname, tag):
     """Every operator with the shipped DCT prior at full size, call by call: the oracle drives a whole Heun-12 trajectory
-    (23 guidance calls, sigma 80 -> 0.01, the inputs of the 256 x 256 fixtures) and the HIP plugin receives
-    the same (x_t, denoiser output, y, sigma) at every call while keeping its own covariance state.  Per call: identical factor count and branch; identical
-    CG iteration counts and outputs within 1e-5 of max|out| wherever the solve is short or sigma <= 3; the rest reported."""
+    (23 guidance calls, sigma 80 -> 0.01, the inputs of the 256 x 256 fixtures) and the HIP plugin receives the same
+    (x_t, denoiser output, y, sigma) at every call while keeping its own covariance state.  Asserted per call:
+      * state parity: identical factor count and branch, and the two covariance states agree on a probe vector to 1e-8
+        (measured <= 1e-9 after 8 space + 11 time updates);
+      * value parity: converged solves (rtol <= 1e-4: the steps that fix the final image) within 1e-5 of max|out|;
+      * system parity for the un-converged solves: at sigma >= 1 the reference stops CG at rtol 0.04 .. 1 on a system of
+        condition ~ 1e6, where the iterate moves by kappa x the 1e-10 state difference (measured: mat differs by 4e-4 after
+        12 equal iterations, the guidance C mat by 4 %; a 2-iteration difference moves it by 60 %).  There the iterate is
+        not a property of the system, so the first three such calls re-solve both sides at rtol 1e-6 and compare THOSE
+        (measured <= 5e-7 of max|mat|; bound 1e-5); the loose outputs get a sanity bound and go to the report."""
     from oracle import fh_oracle as fo, unet_oracle as uo
-    from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate
+    from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate, solve_customcuda
     from test_oracle_golden import _mk_op
     g = gold("trajectories256")
     size, ncalls, nsteps = 256, 23, 12
@@ -447,10 +454,22 @@ def test_teacher_forced_256(dev, gold, opname, tag):
     noise, y = inputs.randn((1, 3, size, size), s_noise, torch.float32), T(g[p + "y"])
     kw = _base_kwargs(DATA, {})
     onet = fo.LinearPrecond(uo.OracleUNet(inputs.SMALL_C, uo.seeded_state(inputs.SMALL_C, int(g["unet_seed"]))))
+    probe = inputs.randn((1, 3, size, size), 99, torch.float64)
     rows = []
 
     class Stop(Exception):
         pass
+
+    def resolve_tight(pair, y_, sigma, rt=1e-6):
+        keep, io, ih = fo.rtol_func, [], []
+        fo.rtol_func = lambda s_, m_: rt
+        try:
+            mo = fo.solve_mat(pair.o.op, y_, pair.o.means[-1], pair.o.cov, 1.0, float(sigma), io)
+        finally:
+            fo.rtol_func = keep
+        mh = solve_customcuda(hop, y_.to(dev), pair.h.denoiser_means[-1], pair.h.covariance_model, 1.0, float(sigma), ih,
+                              rtol=rt)
+        return maxabs(mo, mh) / float(mo.abs().max()), io[0]["niter"], ih[0]["niter"]
 
     class Pair:
         def __init__(self, op_, v0, d):
@@ -468,9 +487,14 @@ def test_teacher_forced_256(dev, gold, opname, tag):
 
             out_h = self.h(x_t.to(dev).clone(), net_dev, y_.to(dev), sigma.to(dev))
             to, th = self.o.trace[-1], self.h.trace[-1]
-            rows.append(dict(sigma=float(sigma), no=to["niter"], nh=th["niter"], bo=to["branch"], bh=th["branch"],
-                             ko=to["k"], kh=th["k"], err=maxabs(out_o, out_h), mag=float(out_o.abs().max()),
-                             rtol=float(th["rtol"])))
+            co = self.o.cov.denoiser_cov_vector_dot(probe)
+            r = dict(sigma=float(sigma), no=to["niter"], nh=th["niter"], bo=to["branch"], bh=th["branch"],
+                     ko=to["k"], kh=th["k"], err=maxabs(out_o, out_h), mag=float(out_o.abs().max()), rtol=float(th["rtol"]),
+                     cov_probe=maxabs(co, self.h.covariance_model.denoiser_cov_vector_dot(probe.to(dev)))
+                     / float(co.abs().max()))
+            if r["rtol"] > 1e-4 and r["err"] > 1e-5 * r["mag"] and sum("tight" in q for q in rows) < 3:
+                r["tight"], r["tight_no"], r["tight_nh"] = resolve_tight(self, y_, sigma)
+            rows.append(r)
             if len(rows) >= ncalls:
                 raise Stop()
             return out_o
@@ -481,23 +505,24 @@ def test_teacher_forced_256(dev, gold, opname, tag):
     except Stop:
         pass
     assert len(rows) == ncalls
-    tight = 0
+    _report(f"{tag}[teacher-forced Heun-12]", {"calls": ncalls, "k_last": rows[-1]["kh"],
+                                             "equal_niter_calls": sum(r["no"] == r["nh"] for r in rows),
+                                             "rows": [{k: (round(v, 12) if isinstance(v, float) else v) for k, v in r.items()}
+                                                      for r in rows]})
+    equal = 0
     for r in rows:
         assert r["ko"] == r["kh"] and r["bo"] == r["bh"], r
-        rel = r["err"] / r["mag"]
-        if r["no"] == r["nh"]:  # every call with equal iteration counts carries a value assertion
-            # converged solves (rtol <= 1e-4, i.e. sigma < 0.2: the steps that fix the final image): 1e-5 of max|out|; short
-            # un-converged solves (<= 20 iterations; rtol is still 0.12 at sigma = 3): 1e-3 (measured up to 1e-4).  Long un-converged solves at high sigma (rtol 0.1 .. 1, up to 250
-            # iterations on a cond ~ 1e6 system): two float64 CG implementations with different summation orders and DCTs
-            # lose orthogonality differently, and the iterate - still far from the solution - differs by percents (measured
-            # 0.8 - 5 % of max|out|, inpainting included, where both operators are exact): a sanity bound, values in the report
-            assert rel < (1e-5 if r["rtol"] <= 1e-4 else (1e-3 if r["no"] <= 20 else 0.5)), r
-            tight += 1
-    _report(f"{tag}[teacher-forced Heun-12]", {"calls": ncalls, "k_last": rows[-1]["kh"], "equal_niter_calls": tight,
-                                             "rows": [{k: (round(v, 10) if isinstance(v, float) else v) for k, v in r.items()}
-                                                      for r in rows]})
+        assert r["cov_probe"] < 1e-8, r
+        if "tight" in r:
+            assert r["tight"] < 1e-5 and abs(r["tight_no"] - r["tight_nh"]) <= 0.05 * r["tight_no"] + 2, r
+        if r["no"] == r["nh"]:
+            equal += 1
+            assert r["err"] / r["mag"] < (1e-5 if r["rtol"] <= 1e-4 else 0.5), r
+        else:
+            assert abs(r["no"] - r["nh"]) <= 0.1 * r["no"] + 2, r
+    assert sum(r["rtol"] <= 1e-4 and r["no"] == r["nh"] for r in rows) >= 4  # the converged tail carries value assertions
+    assert equal >= (2 * ncalls) // 3
     assert rows[-1]["kh"] >= 4
-    assert tight >= (2 * ncalls) // 3
 
 
 def test_groups_equal_single_group(dev):
