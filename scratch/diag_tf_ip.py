@@ -59,6 +59,15 @@ class Pair:
         t2 = fo._apply_rep(self.o.cov.icov, zo).real.contiguous().to(dev)
         r["cross_Ch_Cio"] = float((cm._apply(cm.C, cm.famC, t2, torch.empty_like(zh)).cpu() - z).abs().max())
         r["icovdiff"] = float((t2 - t1).abs().max() / t2.abs().max())
+        if len(rows) in (18, 20, 21):  # dump the C / C^-1 representations around the last time updates
+            cmm = self.h.covariance_model
+            m_ = cmm.famC.m
+            np.savez(f"/tmp/state_{opname}_{len(rows)}.npz", sigma=float(sigma), m=m_,
+                     D=cmm.C.D.cpu().numpy(), r=cmm.C.r.cpu().numpy(), M=cmm.C.M_dev[:m_, :m_].cpu().numpy(),
+                     B=cmm.famC.B[:m_].cpu().numpy(), Di=cmm.Ci.D.cpu().numpy(), ri=cmm.Ci.r.cpu().numpy(),
+                     Mi=cmm.Ci.M_dev[:m_, :m_].cpu().numpy(),
+                     z=z.numpy(), Cz_hip=cmm._apply(cmm.C, cmm.famC, zh, torch.empty_like(zh)).cpu().numpy(),
+                     Cz_orc=fo._apply_rep(self.o.cov.cov, zo).real.numpy())
         print({k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
         rows.append(r)
         if len(rows) >= ncalls: raise Stop()

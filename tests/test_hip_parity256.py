@@ -69,6 +69,69 @@ def test_covariance256_vs_reference_golden(dev, gold):
     assert cov.famC.m == 32
 
 
+
+def _ld_solve(A, Bm):
+    """longdouble Gaussian elimination with partial pivoting (numpy.linalg has no extended precision): A X = Bm"""
+    LD = np.longdouble
+    A, X, n = A.astype(LD).copy(), Bm.astype(LD).copy(), A.shape[0]
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(A[k:, k])))
+        if p != k:
+            A[[k, p]], X[[k, p]] = A[[p, k]], X[[p, k]]
+        for i in range(k + 1, n):
+            f = A[i, k] / A[k, k]
+            A[i, k:] -= f * A[k, k:]
+            X[i] -= f * X[k]
+    for k in range(n - 1, -1, -1):
+        X[k] = (X[k] - A[k, k + 1:] @ X[k + 1:]) / A[k, k]
+    return X
+
+
+def test_forward_time_shift_accuracy_vs_extended_precision(dev, gold, monkeypatch):
+    """The time update C <- (C^-1 + s I)^-1 on the states of a real full-size trajectory (gaussian blur, Heun-30, HIP UNet)
+    against the same formula in 80-bit arithmetic on the CPU, for the updates below sigma = 0.5.  Consecutive sampler steps
+    give nearly dependent factor columns: cond(I + s G M) ~ 1e10 .. 1e13, where a plain float64 elimination - this build
+    before the refinement, and the reference's route through numpy / torch inverses - leaves 1e-6 .. 1e-4 in C.  The m x m
+    solve of k_woodbury_inner is refined with double-double residuals: < 1e-7 of max|C z| (measured 1e-8)."""
+    from free_hunch_amd import covariance as hc
+    LD = np.longdouble
+    g = gold("trajectories256")
+    z = inputs.randn((1, 3, 256, 256), 70, torch.float64).reshape(-1)
+    zd, zl = z.to(dev), z.numpy().astype(LD)
+    checks = []
+    orig = hc.CovarianceHessianBFGSDCT.update_time_step
+
+    def checked(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance=False):
+        m = self.famC.m
+        pre = None
+        if m >= 8 and float(sigma_tnext) < 0.5 and len(checks) < 4:
+            pre = [t.cpu().numpy() for t in (self.C.D, self.C.r, self.C.M_dev[:m, :m], self.famC.B[:m])]
+        out = orig(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance)
+        if pre is not None:
+            sh = float(np.float32(float(sigma_tnext) ** (-2) - float(sigma_t) ** (-2)))
+            res = {}
+            for T_, solve in ((LD, _ld_solve), (np.float64, np.linalg.solve)):
+                D, r, M, B = (a.astype(T_) for a in pre)
+                e = 1 / (1 + T_(sh) * D)
+                K = np.eye(m, dtype=T_) + T_(sh) * (((B * (r * r * e)) @ B.T) @ M)
+                Mp = solve(K.T, M.T).T
+                zz = zl.astype(T_)
+                res[T_] = D * e * zz + r * e * (B.T @ (Mp @ (B @ (r * e * zz))))
+            truth = res[LD]
+            got = self._apply(self.C, self.famC, zd, torch.empty_like(zd)).cpu().numpy()
+            sc = float(np.abs(truth).max())
+            checks.append({"sigma_next": float(sigma_tnext), "m": int(m), "cond": float(np.linalg.cond(K.astype(np.float64))),
+                           "hip": float(np.abs(got - truth).max()) / sc,
+                           "plain_float64": float(np.abs(res[np.float64] - truth).max()) / sc})
+        return out
+
+    monkeypatch.setattr(hc.CovarianceHessianBFGSDCT, "update_time_step", checked)
+    _free_run(g, "gb256_heun30", 256, _small_net(inputs.SMALL_C, int(g["unet_seed"]), dev), dev, DATA, 4, "hip-unet")
+    _report("forward_time_shift_vs_longdouble", {"checks": checks})
+    assert len(checks) == 4
+    assert max(c["hip"] for c in checks) < 1e-7, checks
+
+
 # ---------------------------------------------------------------- a10: 0 < max_vector_count < k
 @pytest.mark.parametrize("tag", ["dct16_max1", "dct16_max3"])
 def test_covariance_truncation_vs_reference_golden(dev, gold, tmp_path, tag):
@@ -432,8 +495,9 @@ def test_teacher_forced_256(dev, gold, opname, tag):
     """Every operator with the shipped DCT prior at full size, call by call: the oracle drives a whole Heun-12 trajectory
     (23 guidance calls, sigma 80 -> 0.01, the inputs of the 256 x 256 fixtures) and the HIP plugin receives the same
     (x_t, denoiser output, y, sigma) at every call while keeping its own covariance state.  Asserted per call:
-      * state parity: identical factor count and branch, and the two covariance states agree on a probe vector to 1e-8
-        (measured <= 1e-9 after 8 space + 11 time updates);
+      * state parity: identical factor count and branch, and the two covariance states agree on a probe vector to 1e-6
+        (measured <= 1.5e-7 after 8 space + 11 time updates; below sigma = 0.2 the reference's own arithmetic is 3e-7 ..
+        1.4e-6 off the exact update, this build 1e-8: test_forward_time_shift_accuracy_vs_extended_precision);
       * value parity: converged solves (rtol <= 1e-4: the steps that fix the final image) within 1e-5 of max|out|;
       * system parity for the un-converged solves: at sigma >= 1 the reference stops CG at rtol 0.04 .. 1 on a system of
         condition ~ 1e6, where the iterate moves by kappa x the 1e-10 state difference (measured: mat differs by 4e-4 after
@@ -512,7 +576,7 @@ def test_teacher_forced_256(dev, gold, opname, tag):
     equal = 0
     for r in rows:
         assert r["ko"] == r["kh"] and r["bo"] == r["bh"], r
-        assert r["cov_probe"] < 1e-8, r
+        assert r["cov_probe"] < 1e-6, r  # measured <= 1.5e-7; the reference's own float64 arithmetic is 3e-7 .. 1.4e-6 off there
         if "tight" in r:
             assert r["tight"] < 1e-5 and abs(r["tight_no"] - r["tight_nh"]) <= 0.05 * r["tight_no"] + 2, r
         if r["no"] == r["nh"]:
