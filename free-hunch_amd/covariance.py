@@ -98,7 +98,18 @@ def _woodbury_inner(M, G):
     m = M.shape[0]
     if m == 0:
         return M
-    out = -M @ np.linalg.inv(np.eye(m) + G @ M)
+    # as k_woodbury_inner: I + G M is ill-conditioned on real trajectories (nearly dependent columns); float64 inverse, then
+    # iterative refinement of X A = -M with extended-precision residuals
+    LD = np.longdouble
+    A = np.eye(m, dtype=LD) + G.astype(LD) @ M.astype(LD)
+    Ainv = np.linalg.inv(A.astype(np.float64))
+    out, prev = -M @ Ainv, np.inf
+    for _ in range(12):
+        R = (-M.astype(LD) - out.astype(LD) @ A).astype(np.float64)
+        cur = float(np.abs(R).max())
+        if not cur < prev:
+            break
+        out, prev = out + R @ Ainv, cur
     return 0.5 * (out + out.T)
 
 

@@ -502,7 +502,7 @@ def test_teacher_forced_256(dev, gold, opname, tag):
       * system parity for the un-converged solves: at sigma >= 1 the reference stops CG at rtol 0.04 .. 1 on a system of
         condition ~ 1e6, where the iterate moves by kappa x the 1e-10 state difference (measured: mat differs by 4e-4 after
         12 equal iterations, the guidance C mat by 4 %; a 2-iteration difference moves it by 60 %).  There the iterate is
-        not a property of the system, so the first three such calls re-solve both sides at rtol 1e-6 and compare THOSE
+        not a property of the system, so the first two such calls re-solve both sides at rtol 1e-6 and compare THOSE
         (measured <= 5e-7 of max|mat|; bound 1e-5); the loose outputs get a sanity bound and go to the report."""
     from oracle import fh_oracle as fo, unet_oracle as uo
     from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate, solve_customcuda
@@ -556,7 +556,7 @@ def test_teacher_forced_256(dev, gold, opname, tag):
                      ko=to["k"], kh=th["k"], err=maxabs(out_o, out_h), mag=float(out_o.abs().max()), rtol=float(th["rtol"]),
                      cov_probe=maxabs(co, self.h.covariance_model.denoiser_cov_vector_dot(probe.to(dev)))
                      / float(co.abs().max()))
-            if r["rtol"] > 1e-4 and r["err"] > 1e-5 * r["mag"] and sum("tight" in q for q in rows) < 3:
+            if r["rtol"] > 1e-4 and r["err"] > 1e-5 * r["mag"] and sum("tight" in q for q in rows) < 2:
                 r["tight"], r["tight_no"], r["tight_nh"] = resolve_tight(self, y_, sigma)
             rows.append(r)
             if len(rows) >= ncalls:
