@@ -400,12 +400,13 @@ static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, in
 // ------------------------------------------------------------------------------------------------
 typedef double d2v_t __attribute__((ext_vector_type(2)));  // native vector type: usable with the nontemporal builtins
 constexpr int kDotRows = 768;   // rows per workgroup (d = 196608 -> 256 workgroups, one per CU)
-constexpr int kColChunk = 8;    // columns held in registers per wave and sweep
+constexpr int kColChunk = 4;    // columns held in registers per wave and sweep
 
 // pass 1: the 4 waves of a workgroup split the columns (wave w owns columns w, w+4, ...), lanes run along the
 // rows with 16-byte loads.  The column loads are branch-free (out-of-range columns re-read column m-1 and are
-// dropped at the end) so that a wave has (768/128) x 8 independent 1-KiB loads in flight: 4.7 TB/s on the 50 MB
-// base at m = 32 (a pure streaming read of the same bytes reaches 5.6 TB/s).  Each wave writes its sums as block
+// dropped at the end) so that a wave has (768/128) x 4 independent 1-KiB loads in flight (8 per wave cost 248 VGPRs,
+// two waves per SIMD and 71 us per 403 MB sweep at 8 images; 4 -> four waves per SIMD, 66 us; a pure streaming read of
+// the same bytes with this access pattern takes 61 us, profiles/r02_cov_apply_single_sweep.md).  Each wave writes its sums as block
 // partials; k_rep_coef (one 1024-thread workgroup) adds them in a fixed order and forms c = M t.  (float64 atomics
 // into a shared m-vector were measured 2x SLOWER than this: 8192 same-address adds serialise at the memory side.)
 // NT: non-temporal loads of B.  A base that does not fit the 256 MB Infinity Cache anyway (8 images x 32 columns = 403 MB)
@@ -415,6 +416,12 @@ template <bool NT>
 __device__ __forceinline__ d2v_t ld_base(const double* p) {
   if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p));
   return *reinterpret_cast<const d2v_t*>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ double ld_base1(const double* p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
 }
 
 template <bool NT>
@@ -533,48 +540,55 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
   for (int j = tid; j < m; j += 256) c[j] = coef[j];
   __syncthreads();
   const int64_t blk = (int64_t)gridDim.x - 1 - blockIdx.x;  // reverse sweep
-  for (int64_t i0 = blk * kDotRows + 2 * tid; i0 < (blk + 1) * kDotRows && i0 + 1 < d; i0 += 512) {
-    // canonical summation order of (B c)_i, shared with the single-sweep kernel k_rep_fused (whose 8 waves each own the
-    // columns j = w (mod 8)): eight chains over j = w, w + 8, ... then the chains added in the order w = 0 .. 7
-    double2 ch[8];
+  // every thread owns three rows of the block (row = block start + 256 q + tid: coalesced 8-byte loads): equal work for the
+  // 256 threads, any d (the former row-pair mapping needed an even d and left half of the lanes idle in a second trip)
+  constexpr int kR = kDotRows / 256;
+  int64_t row[kR];
+  bool ok[kR];
 #pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) ch[w8] = make_double2(0.0, 0.0);
-    const int mfull = m & ~7;
-    for (int j0 = 0; j0 < mfull; j0 += 8) {  // eight independent streaming loads per step
-      d2v_t b[8];
+  for (int q = 0; q < kR; ++q) {
+    const int64_t i = blk * kDotRows + 256 * q + tid;
+    ok[q] = i < d;
+    row[q] = ok[q] ? i : 0;
+  }
+  // canonical summation order of (B c)_i, shared with the single-sweep kernel k_rep_fused (whose 8 waves each own the
+  // columns j = w (mod 8)): eight chains over j = w, w + 8, ... then the chains added in the order w = 0 .. 7
+  double ch[8][kR];
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8)
-        b[w8] = ld_base<NT>(B + (int64_t)(j0 + w8) * d + i0);
+  for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) {
-        const double cj = c[j0 + w8];
-        ch[w8].x = fma(b[w8].x, cj, ch[w8].x);
-        ch[w8].y = fma(b[w8].y, cj, ch[w8].y);
-      }
-    }
+    for (int q = 0; q < kR; ++q) ch[w8][q] = 0.0;
+  const int mfull = m & ~7;
+  for (int j0 = 0; j0 < mfull; j0 += 8) {  // 24 independent streaming loads per step
+    double b[8][kR];
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8)
+#pragma unroll
+      for (int q = 0; q < kR; ++q) b[w8][q] = ld_base1<NT>(B + (int64_t)(j0 + w8) * d + row[q]);
 #pragma unroll
     for (int w8 = 0; w8 < 8; ++w8) {
-      const int j = mfull + w8;
-      if (j < m) {
-        const d2v_t b = ld_base<NT>(B + (int64_t)j * d + i0);
-        const double cj = c[j];
-        ch[w8].x = fma(b.x, cj, ch[w8].x);
-        ch[w8].y = fma(b.y, cj, ch[w8].y);
-      }
-    }
-    double2 acc = ch[0];
+      const double cj = c[j0 + w8];
 #pragma unroll
-    for (int w8 = 1; w8 < 8; ++w8) acc.x += ch[w8].x, acc.y += ch[w8].y;
-    const double2 zz = *reinterpret_cast<const double2*>(z + i0);
-    const double2 dd = *reinterpret_cast<const double2*>(D + i0);
-    double2 o;
-    if (m > 0) {
-      const double2 rr = *reinterpret_cast<const double2*>(r + i0);
-      o = make_double2(fma(rr.x, acc.x, dd.x * zz.x), fma(rr.y, acc.y, dd.y * zz.y));
-    } else {
-      o = make_double2(dd.x * zz.x, dd.y * zz.y);
+      for (int q = 0; q < kR; ++q) ch[w8][q] = fma(b[w8][q], cj, ch[w8][q]);
     }
-    *reinterpret_cast<double2*>(out + i0) = o;
+  }
+#pragma unroll
+  for (int w8 = 0; w8 < 8; ++w8) {
+    const int j = mfull + w8;
+    if (j < m) {
+      const double cj = c[j];
+#pragma unroll
+      for (int q = 0; q < kR; ++q) ch[w8][q] = fma(ld_base1<NT>(B + (int64_t)j * d + row[q]), cj, ch[w8][q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kR; ++q) {
+    double acc = ch[0][q];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) acc += ch[w8][q];
+    const double zz = z[row[q]], dd = D[row[q]];
+    const double o = m > 0 ? fma(r[row[q]], acc, dd * zz) : dd * zz;
+    if (ok[q]) out[row[q]] = o;
   }
 }
 
