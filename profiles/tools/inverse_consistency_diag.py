@@ -1,7 +1,8 @@
 import os, sys
 import numpy as np, torch
-sys.path[:0] = ["/root/repo", "/root/repo/tests", "/root/repo/tests/golden"]
-os.chdir("/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/tests/golden"]
+os.chdir(ROOT)
 import inputs
 import test_hip_parity as tp
 from oracle import fh_oracle as fo

@@ -1,8 +1,9 @@
 """diagnostic: teacher-forced ip256 Heun-12; for calls with equal iteration counts and rel > 1e-5, re-solve both sides tightly"""
 import os, sys, json
 import numpy as np, torch
-sys.path[:0] = ["/root/repo", "/root/repo/tests", "/root/repo/tests/golden"]
-os.chdir("/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, ROOT + "/tests", ROOT + "/tests/golden"]
+os.chdir(ROOT)
 import test_hip_parity256 as t
 from test_oracle_golden import _mk_op
 import inputs
