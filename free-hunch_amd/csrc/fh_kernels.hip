@@ -1274,6 +1274,73 @@ __global__ __launch_bounds__(256) void k_conv_tile(const double* __restrict__ in
   }
 }
 
+// k_conv_tile8: the stride-1 case with 8 outputs per thread - a 64 x 32 output tile, thread = 2 columns (16 apart) x 4 rows
+// (16 apart).  k_conv_tile issues 4 LDS instructions per 2 multiply-adds (offset, weight, two inputs) and is bound by
+// the LDS instruction rate (10 % of the f64 FMA rate on the 217-tap motion PSF); here a tap costs one 16-byte broadcast
+// read (weight + offset packed) and four two-address reads for 8 multiply-adds, and the halo is amortised over 4x the
+// outputs (2.9x the tile instead of 6.9x at the motion PSF's 58 x 16 extent).  Same tap order per output: same result.
+constexpr int kT8W = 32, kT8H = 64;
+
+__global__ __launch_bounds__(256) void k_conv_tile8(const double* __restrict__ in, double* __restrict__ out,
+                                                    const int* __restrict__ tdy, const int* __restrict__ tdx,
+                                                    const double* __restrict__ tw, int ntaps, int S, int halo,
+                                                    int halo_x, int adjoint, const double* __restrict__ add,
+                                                    double add_scale, const fh_cg_state* __restrict__ states) {
+  IMG_GUARD(states, blockIdx.z / 3);
+  extern __shared__ __align__(16) double tile[];  // [sh*sw (+1)] tile | [ntaps] (weight, offset) pairs
+  const int sw = kT8W + 2 * halo_x, sh = kT8H + 2 * halo;
+  double2* s_tap = reinterpret_cast<double2*>(tile + ((sw * sh + 1) & ~1));
+  const int plane = blockIdx.z;
+  const int oy0 = blockIdx.y * kT8H, ox0 = blockIdx.x * kT8W;
+  const double* src = in + (int64_t)plane * S * S;
+  const int sgn = adjoint ? 1 : -1;
+  for (int t = threadIdx.x; t < ntaps; t += 256)
+    s_tap[t] = make_double2(tw[t], __longlong_as_double((long long)(sgn * (tdy[t] * sw + tdx[t]))));
+  for (int ly = threadIdx.x >> 6; ly < sh; ly += 4) {  // a wave per tile row: no division by the run-time row pitch
+    int gy = (oy0 + ly - halo) % S;
+    gy += gy < 0 ? S : 0;
+    const double* srow = src + (int64_t)gy * S;
+    for (int lx = threadIdx.x & 63; lx < sw; lx += 64) {
+      int gx = (ox0 + lx - halo_x) % S;
+      gx += gx < 0 ? S : 0;
+      tile[ly * sw + lx] = srow[gx];
+    }
+  }
+  __syncthreads();
+  // thread = columns tx and tx + 16, rows ty + 16 r: 16 lanes read 16 consecutive doubles (all 32 banks of a half), the next
+  // 16 lanes the next tile row - adjacent column PAIRS per lane would leave half of the banks idle in every pass
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const double* q = tile + (ty + halo) * sw + tx + halo_x;
+  const int rstep = 16 * sw;
+  double a[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) a[r][0] = a[r][1] = 0.0;
+#pragma unroll 2
+  for (int t = 0; t < ntaps; ++t) {
+    const double2 tp = s_tap[t];
+    const double* p = q + (int)__double_as_longlong(tp.y);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r][0] = fma(tp.x, p[r * rstep], a[r][0]);
+      a[r][1] = fma(tp.x, p[r * rstep + 16], a[r][1]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oy = oy0 + ty + 16 * r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ox = ox0 + tx + 16 * e;
+      if (oy < S && ox < S) {
+        const int64_t o = (int64_t)plane * S * S + (int64_t)oy * S + ox;
+        double v = a[r][e];
+        if (add != nullptr) v = fma(add_scale, add[o], v);
+        out[o] = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ in, double* __restrict__ out,
                                                      const int* __restrict__ tdy, const int* __restrict__ tdx,
                                                      const double* __restrict__ tw, int ntaps, int S, int stride,
@@ -1581,6 +1648,13 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
                        const double* w, int ntaps, int halo, int planes, int stride, int adjoint, const double* add,
                        double add_scale, const fh_cg_state* done, hipStream_t st) {
   const int S = ctx->S;
+  // halo encodings: h = max(|dy|,|dx|) <= 32;  -(h+1) / -(h+101): 1-D column / row tap list;  1000 + 64 hy + hx: both extents
+  int hy2 = -1, hx2 = -1;
+  if (halo >= 1000) {
+    hy2 = (halo - 1000) / 64, hx2 = (halo - 1000) % 64;
+    if (hy2 > 32 || hx2 > 32) return FH_EINVAL;
+    halo = hy2 > hx2 ? hy2 : hx2;
+  }
   if (stride < 1 || S % stride != 0 || halo < -133 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
   if (!adjoint && stride > 1) {
     const int So = S / stride;
@@ -1590,6 +1664,7 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
   } else {
     // halo = max(|dy|,|dx|); negative values encode 1-D tap lists: -(h+1) = column kernel (dx = 0), -(h+101) = row kernel
     int hy = halo, hx = halo;
+    if (hy2 >= 0) hy = hy2, hx = hx2;
     if (halo <= -101) hy = 0, hx = -halo - 101;
     else if (halo < 0) hy = -halo - 1, hx = 0;
     if (halo < 0 && stride == 1 && S % 2 == 0) {  // 1-D pass at full resolution: register-blocked kernel
@@ -1606,6 +1681,16 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
           hipLaunchKernelGGL(k_conv1d<1>, grid, dim3(256), lds1, st, in, out, dx, w, ntaps, S, h, adjoint, add, add_scale,
                              done);
         }
+        FH_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    if (stride == 1) {  // 8 outputs per thread when the 64 x 32 tile with its halo fits
+      const size_t lds8 = (((size_t)(kT8W + 2 * hx) * (kT8H + 2 * hy) + 1) & ~(size_t)1) * sizeof(double) + (size_t)ntaps * 16;
+      if (lds8 <= 64 * 1024) {
+        dim3 grid8((S + kT8W - 1) / kT8W, (S + kT8H - 1) / kT8H, planes);
+        hipLaunchKernelGGL(k_conv_tile8, grid8, dim3(256), lds8, st, in, out, dy, dx, w, ntaps, S, hy, hx, adjoint, add,
+                           add_scale, done);
         FH_LAUNCH_CHECK();
         return 0;
       }

@@ -47,9 +47,9 @@ class _TapList:
         cy, cx = k.shape[0] // 2, k.shape[1] // 2
         self.n = int(ys.size)
         hy, hx = int(np.abs(ys - cy).max()), int(np.abs(xs - cx).max())
-        # fh_conv_circ halo code: max extent, or for 1-D lists -(h+1) (column kernel, dx = 0) / -(h+101) (row kernel),
-        # which lets the kernel skip the halo of the unused direction
-        self.halo = -(hy + 1) if (hx == 0 and hy > 0) else (-(hx + 101) if (hy == 0 and hx > 0) else max(hy, hx))
+        # fh_conv_circ halo code: for 1-D lists -(h+1) (column kernel, dx = 0) / -(h+101) (row kernel), else both extents
+        # (1000 + 64 hy + hx), so that the kernel stages only the halo the taps reach
+        self.halo = -(hy + 1) if (hx == 0 and hy > 0) else (-(hx + 101) if (hy == 0 and hx > 0) else 1000 + 64 * hy + hx)
         self.dy = torch.from_numpy((ys - cy).astype(np.int32)).to(device)
         self.dx = torch.from_numpy((xs - cx).astype(np.int32)).to(device)
         self.w = torch.from_numpy(np.ascontiguousarray(k[ys, xs], dtype=np.float64)).to(device)

@@ -155,7 +155,8 @@ int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k
  *   adjoint = 1:  out[p][i][j] = sum_t w[t] * up(in)[(i + dy[t]) mod S][(j + dx[t]) mod S]
  *                 (in is [planes][S/stride][S/stride], zero-inserted on the fly)
  * halo = max(|dy|, |dx|) over the taps (<= 32); 1-D tap lists may pass -(h+1) (column kernel, all dx = 0) or
- * -(h+101) (row kernel, all dy = 0) so that only the needed halo is staged.
+ * -(h+101) (row kernel, all dy = 0), 2-D lists 1000 + 64 * max|dy| + max|dx|, so that only the needed halo is staged
+ * (the shipped motion PSF spans 58 x 16: a third of the square halo).
  * Equals ifft2(FB * fft2(x)).real / ifft2(conj(FB) * fft2(x)).real of the reference. */
 int fh_conv_circ(fh_context* ctx, const double* in, double* out, const int32_t* dy, const int32_t* dx,
                  const double* w, int ntaps, int halo, int planes, int stride, int adjoint, void* stream);
@@ -169,7 +170,7 @@ typedef struct fh_problem {
   int32_t ntaps;
   int32_t m;             /* factor columns in use */
   int32_t ldm;
-  int32_t halo;          /* max(|dy|,|dx|) over the taps */
+  int32_t halo;          /* max(|dy|,|dx|) over the taps, or one of the encodings of fh_conv_circ */
   int64_t d;             /* planes*S*S */
   double sigma_y2;       /* measurement-noise variance after the reference's clips */
   const int32_t* tap_dy; /* [ntaps] */
