@@ -1176,6 +1176,8 @@ __global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restric
 // ------------------------------------------------------------------------------------------------
 // mode 0: 2x2 average pool  [N][H][W][C] -> [N][H/2][W/2][C]        mode 1: its adjoint (grad / 4 to 4 pixels)
 // mode 2: nearest 2x upsample [N][H][W][C] -> [N][2H][2W][C]        mode 3: its adjoint (sum of 4 grads)
+// mode 4: zero insertion small -> big (out[2h][2w] = in[h][w], 0 elsewhere): the cotangent of a stride-2 convolution before
+//         its stride-1 input-gradient pass (Downsample with conv_resample, openai_unet.py:131)
 __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ in, float* __restrict__ out, int N, int H,
                                                   int W, int C, int mode) {
   // H, W are always the SMALL side's dimensions
@@ -1196,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ in, 
       const int w = (int)(p % (2 * W)), h = (int)((p / (2 * W)) % (2 * H)), n = (int)(p / ((int64_t)4 * W * H));
       float4 v = reinterpret_cast<const float4*>(in)[(((int64_t)n * H + h / 2) * W + w / 2) * C4 + c4];
       if (mode == 1) v = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
+      if (mode == 4 && ((h | w) & 1)) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero insertion: only (even, even) carries a value
       reinterpret_cast<float4*>(out)[i] = v;
     }
   }
@@ -1546,7 +1549,7 @@ int fh_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int T, void* st
 }
 
 int fh_resample2x(const float* in, float* out, int N, int Hs, int Ws, int C, int mode, void* stream) {
-  if (!in || !out || C % 4 != 0 || mode < 0 || mode > 3) return FH_EINVAL;
+  if (!in || !out || C % 4 != 0 || mode < 0 || mode > 4) return FH_EINVAL;
   const int64_t items = (int64_t)N * Hs * Ws * (C / 4) * ((mode == 0 || mode == 3) ? 1 : 4);
   hipLaunchKernelGGL(k_resample, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, in, out, N, Hs, Ws, C, mode);
   FH_LAUNCH_CHECK();

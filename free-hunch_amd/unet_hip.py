@@ -104,13 +104,24 @@ class HipOps:
         self._tls = threading.local()  # emb_key: the timestep tuple of the call running on THIS host thread
 
     # ---------------------------------------------------------------- kernel wrappers
-    def _conv(self, name, x, res=None, bias_override=None):
+    def _conv(self, name, x, res=None, bias_override=None, stride=1):
         c = self.conv[name]
         N, H, W, Ci = x.shape
         assert Ci == c.ci_p, (name, x.shape, c.ci_p)
         pad = c.kh // 2
-        out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
         b = c.b if bias_override is None else bias_override
+        if stride != 1:  # Downsample(use_conv=True), openai_unet.py:131: 3x3, stride 2, padding 1
+            Ho, Wo = (H + 2 * pad - c.kh) // stride + 1, (W + 2 * pad - c.kw) // stride + 1
+            out = torch.empty(N, Ho, Wo, c.co, dtype=torch.float32, device=x.device)
+            ks = self.lib.fh_conv2d_splitk(N, Ho, Wo, Ci, c.co, c.kh, c.kw)
+            ws = torch.empty(ks, N * Ho * Wo, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
+            fn, wgt = ((self.lib.fh_conv2d_x6_nhwc, c.wx_f) if c.wx_f is not None and _use_x6(N, Ho, Wo, c.co)
+                       else (self.lib.fh_conv2d_nhwc, c.wf))
+            _lib.check(fn(x.data_ptr(), wgt.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(),
+                          out.data_ptr(), None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh, c.kw, pad,
+                          stride, _lib.stream()), "fh_conv2d(stride)")
+            return out
+        out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
         if c.wu_f is not None and _use_wino(N, H, W, Ci, c.co):
             _lib.check(self.lib.fh_conv3x3_wino_nhwc(x.data_ptr(), c.wu_f.data_ptr(), b.data_ptr(),
                                                      None if res is None else res.data_ptr(), out.data_ptr(), N, H, W,
@@ -226,7 +237,7 @@ class HipOps:
 
     def _resample(self, x, mode):
         N, H, W, C = x.shape
-        hs, ws = (H // 2, W // 2) if mode in (0, 3) else (H, W)
+        hs, ws = (H // 2, W // 2) if mode in (0, 3) else (H, W)  # modes 1, 2, 4 go small -> big
         oh, ow = (hs, ws) if mode in (0, 3) else (2 * H, 2 * W)
         out = torch.empty(N, oh, ow, C, dtype=torch.float32, device=x.device)
         _lib.check(self.lib.fh_resample2x(x.data_ptr(), out.data_ptr(), N, hs, ws, C, mode, _lib.stream()), "resample")
@@ -379,9 +390,20 @@ class HipOps:
                 h = self._res_fwd(op, p, h, emb, tape)
             elif op == "attn":
                 h = self._attn_fwd(p, h, heads, tape)
+            elif op == "down":  # Downsample, openai_unet.py:114-139 (the public 256 x 256 checkpoints use res_down instead)
+                if cfg.conv_resample:
+                    h = self._conv(p + ".op", h, stride=2)
+                    tape.append(("down_conv", p + ".op"))
+                else:
+                    h = self._resample(h, 0)
+                    tape.append(("down_pool",))
+            elif op == "up":  # Upsample, openai_unet.py:77-111: nearest x2, then the 3x3 convolution
+                h = self._resample(h, 2)
+                if cfg.conv_resample:
+                    h = self._conv(p + ".conv", h)
+                tape.append(("up", p + ".conv" if cfg.conv_resample else None))
             else:
-                raise NotImplementedError(f"UNet step '{op}' (conv_resample up/down-sampling) has no HIP kernel yet; "
-                                          "the public 256x256 checkpoints use resblock_updown")
+                raise NotImplementedError(f"UNet step '{op}'")
         hn, stn = self._gn("out.0", h, act=1)
         tape.append(("out", h, stn))
         y = self._conv("out.2", hn)  # [N,H,W,out_channels]
@@ -420,6 +442,14 @@ class HipOps:
                 g = ga
             elif kind == "push":
                 g = self._add(g, pending.pop())
+            elif kind == "down_conv":  # stride-2 convolution: zero-inserted cotangent through the stride-1 input-gradient pass
+                g = self._dgrad(rec[1], self._resample(g, 4))
+            elif kind == "down_pool":
+                g = self._resample(g, 1)
+            elif kind == "up":
+                if rec[1] is not None:
+                    g = self._dgrad(rec[1], g)
+                g = self._resample(g, 3)
             elif kind == "conv":
                 g = self._dgrad(rec[1], g)  # [N,H,W,3]
         ci = g.shape[-1]

@@ -252,7 +252,7 @@ int fh_cg_solve_batched(fh_context* ctx, const fh_problem* shared, const fh_batc
  *   conv3x3 / conv1x1 / their input gradients   openai_unet.py:98,131,185,211,222,286,294   -> fh_conv2d_nhwc
  *   GroupNorm32 (+ scale/shift, + SiLU)          openai_nn.py:17-19, openai_unet.py:182-186,246-252 -> fh_groupnorm_*
  *   QKV attention (both channel orders)          openai_unet.py:337-354, 370-384          -> fh_bgemm_f32 + fh_softmax_*
- *   Upsample / AvgPool2d of resblock_updown      openai_unet.py:107,136                   -> fh_resample2x
+ *   Upsample / AvgPool2d (resblock_updown and the Upsample / Downsample layers)  openai_unet.py:93-139 -> fh_resample2x
  *   torch.cat of the skip connections            openai_unet.py:683                       -> fh_concat_channels
  * ------------------------------------------------------------------------------------------------------------- */
 
@@ -325,7 +325,7 @@ int fh_softmax_rows(float* s, int64_t rows, int T, void* stream);
 int fh_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int T, void* stream);
 
 /* (Hs, Ws) = the SMALL side.  mode 0: 2x2 average pool big -> small; 1: its adjoint small -> big;
- * 2: nearest 2x upsample small -> big; 3: its adjoint big -> small. */
+ * 2: nearest 2x upsample small -> big; 3: its adjoint big -> small; 4: zero insertion small -> big (value at (2h, 2w)). */
 int fh_resample2x(const float* in, float* out, int N, int Hs, int Ws, int C, int mode, void* stream);
 
 /* split = 0: out[p] = [a[p] | b[p]] over P pixels;  split = 1: a, b <- the two channel ranges of out */

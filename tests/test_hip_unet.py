@@ -105,7 +105,8 @@ def _pair(cfg_o, seed, dev):
     from free_hunch_amd import unet as hu
     kw = {k: getattr(cfg_o, k) for k in ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma",
                                          "attention_resolutions", "num_heads", "num_head_channels",
-                                         "use_scale_shift_norm", "resblock_updown", "use_new_attention_order")}
+                                         "use_scale_shift_norm", "resblock_updown", "use_new_attention_order",
+                                         "conv_resample")}
     cfg = hu.UNetConfig(**kw)
     sd = hu.seeded_state(cfg, seed)
     nets = []
@@ -120,9 +121,10 @@ NEW_ORDER = inputs.SMALL_A.__class__(**{**inputs.SMALL_A.__dict__, "use_new_atte
                                         "use_scale_shift_norm": False})
 
 
-@pytest.mark.parametrize("which", ["A", "A_new_order_plain_norm"])
+@pytest.mark.parametrize("which", ["A", "A_new_order_plain_norm", "B_conv_resample", "B_pool_resample"])
 def test_unet_hip_vs_torch_backend(dev, which):
-    cfg_o = inputs.SMALL_A if which == "A" else NEW_ORDER
+    cfg_o = {"A": inputs.SMALL_A, "A_new_order_plain_norm": NEW_ORDER, "B_conv_resample": inputs.SMALL_B,
+             "B_pool_resample": inputs.SMALL_B.__class__(**{**inputs.SMALL_B.__dict__, "conv_resample": False})}[which]
     (hip, ref), cfg = _pair(cfg_o, 11, dev)
     x = (inputs.randn((2, 3, 64, 64), 3, torch.float32) * 0.7).to(dev)
     t = torch.tensor([500, 500], device=dev)
@@ -137,25 +139,33 @@ def test_unet_hip_vs_torch_backend(dev, which):
     assert rel(outs[0][1], outs[1][1]) < 5e-4
 
 
-def test_unet_hip_vs_reference_golden(dev, gold):
+@pytest.mark.parametrize("tag,cfg_o", [("unet_a", inputs.SMALL_A), ("unet_b", inputs.SMALL_B)])
+def test_unet_hip_vs_reference_golden(dev, gold, tag, cfg_o):
     """Raw UNet output, preconditioned denoiser and its input-VJP against vectors produced by the reference's own
-    UNetModel / iDDPMLinearPrecond (tests/golden/unet_a.npz)."""
+    UNetModel / iDDPMLinearPrecond: tests/golden/unet_a.npz (scale-shift norm, legacy attention order, learn_sigma) and
+    unet_b.npz (plain norm, new attention order, 3 output channels - the denoiser formed as the reference's wrapper does)."""
     from free_hunch_amd.precond import iDDPMLinearPrecond
-    g = gold("unet_a")
+    g = gold(tag)
     seed = int(g["seed"])
-    (hip, _), cfg = _pair(inputs.SMALL_A, seed, dev)
-    net = iDDPMLinearPrecond(hip, 64, 3).to(dev)
+    (hip, _), cfg = _pair(cfg_o, seed, dev)
+    net = iDDPMLinearPrecond(hip, 64, 3).to(dev) if cfg_o.learn_sigma else None
     x = (inputs.randn((1, 3, 64, 64), seed + 100) * 3.0).to(dev)
     for j in range(3):
         sigma = torch.tensor(float(g[f"sigma_{j}"]), dtype=torch.float64, device=dev)
+        tstep = torch.from_numpy(g[f"tstep_{j}"]).long().flatten().to(dev)
+        c_in = 1 / (sigma ** 2 + 1).sqrt()
         with torch.no_grad():
-            c_in = 1 / (sigma ** 2 + 1).sqrt()
-            raw = hip(c_in.float() * x.float(), torch.from_numpy(g[f"tstep_{j}"]).long().flatten().to(dev))
+            raw = hip(c_in.float() * x.float(), tstep)
         ref = torch.from_numpy(g[f"raw_{j}"]).to(dev)
         assert rel(raw, ref) < 5e-4
         xt = x.clone().requires_grad_()
-        D, var = net(xt, sigma)
-        assert float((D - torch.from_numpy(g[f"D_{j}"]).to(dev)).abs().max()) < 1e-3
+        if net is not None:
+            D, var = net(xt, sigma)
+        else:
+            D = xt.float() - sigma.float() * hip(c_in.float() * xt.float(), tstep)
+        Dref = torch.from_numpy(g[f"D_{j}"]).to(dev)
+        assert D.dtype == Dref.dtype
+        assert float((D - Dref).abs().max()) < 1e-3
         cot = inputs.randn(D.shape, seed + 200 + j).to(D.dtype).to(dev)
         (vjp,) = torch.autograd.grad((cot * D).sum(), xt)
         assert rel(vjp, torch.from_numpy(g[f"vjp_{j}"]).to(dev)) < 2e-3
