@@ -256,8 +256,15 @@ def roofline_conv_mfma(device, iters=20):
     t6, t32 = timed(f_x6), timed(f_32)
     flops = 2.0 * N * H * W * Ci * Co * k * k
     ach = 6 * flops / t6 / 1e12
-    return {"bound": "mfma", "kernel": "k_conv_x6r<128> 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
-            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+    traffic = None  # HBM-side bytes per launch from the committed PMC passes (profiles/tools/pmc_conv.sh), if present
+    pmc = os.path.join(ROOT, "profiles", "r02_conv_pmc.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f_:
+            per = json.load(f_).get("traffic_bytes_per_launch", {})
+        traffic = next((v for k_, v in per.items() if k_.startswith("k_conv_x6r")), None)
+    return {"bound": "mfma", "kernel": "k_conv_x6r<256,false,256,3> 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
+            "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
+            "algorithmic_bytes": int(2 * N * H * W * 128 * 4 + 3 * 2 * Ci * Co * k * k),
             "flops_per_launch": 6 * flops, "us_per_launch": round(t6 * 1e6, 1),
             "fp32_equivalent_tflops": round(flops / t6 / 1e12, 1),
             "fp32_mfma_kernel": {"kernel": "k_conv_igemm<2,2> (v_mfma_f32_32x32x2_f32)", "achieved": round(flops / t32 / 1e12, 1),
