@@ -1367,6 +1367,145 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Super-resolution operator pair at full rate (stride s = scale factor, 25 x 25 bicubic PSF, not separable):
+//   k_conv_dec : out[i][j] = sum_t w_t in[s i - dy_t][s j - dx_t]          (blur, then keep every s-th sample)
+//   k_conv_up  : out[y][x] = sum_t w_t z[y + dy_t][x + dx_t],  z = u with s - 1 zeros inserted   (its adjoint)
+// k_conv_direct fetched every operand of its 625 taps per output through the vector memory path (131 us per call over 24
+// planes), and k_conv_tile with `up` multiplied the inserted zeros (15 of 16 taps at s = 4; 107 us).  Here the input tile
+// of k_conv_dec sits in LDS de-interleaved by column phase (x = s X + px), so that 16 neighbouring outputs read 16
+// consecutive doubles for every tap; k_conv_up sorts the taps by output phase (py, px) = (-dy mod s, -dx mod s) once per
+// workgroup - one wave, ballots + prefix counts, list order preserved - and every output then visits only the ~ 1/s^2 of
+// the taps that meet a sample of u.  Both keep the tap order of the kernels they replace (skipping exact zeros): the
+// results are bitwise the same.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_dec(const double* __restrict__ in, double* __restrict__ out,
+                                                  const int* __restrict__ tdy, const int* __restrict__ tdx,
+                                                  const double* __restrict__ tw, int ntaps, int S, int s, int hy, int hx,
+                                                  const double* __restrict__ add, double add_scale,
+                                                  const fh_cg_state* __restrict__ states) {
+  IMG_GUARD(states, blockIdx.z / 3);
+  extern __shared__ __align__(16) double tile[];  // [s][R][Wp] input tile by column phase | [ntaps] (weight, offset)
+  const int So = S / s, hq = (hx + s - 1) / s, hx4 = hq * s;
+  const int R = 15 * s + 1 + 2 * hy, Wp = 16 + 2 * hq + 1;
+  double2* s_tap = reinterpret_cast<double2*>(tile + ((s * R * Wp + 1) & ~1));
+  const int plane = blockIdx.z, oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+  const double* src = in + (int64_t)plane * S * S;
+  for (int t = threadIdx.x; t < ntaps; t += 256) {
+    const int c = hx4 - tdx[t];  // column of the tap's operand for output column 0, >= 0
+    s_tap[t] = make_double2(tw[t], __longlong_as_double((long long)(((c % s) * R + hy - tdy[t]) * Wp + c / s)));
+  }
+  const int gy0 = oy0 * s - hy, gx0 = ox0 * s - hx4, ncol = s * (16 + 2 * hq);
+  for (int r = threadIdx.x >> 6; r < R; r += 4) {
+    int gy = (gy0 + r) % S;
+    gy += gy < 0 ? S : 0;
+    const double* srow = src + (int64_t)gy * S;
+    for (int c = threadIdx.x & 63; c < ncol; c += 64) {
+      int gx = (gx0 + c) % S;
+      gx += gx < 0 ? S : 0;
+      tile[((c % s) * R + r) * Wp + c / s] = srow[gx];
+    }
+  }
+  __syncthreads();
+  const int tj = threadIdx.x & 15, ti = threadIdx.x >> 4;
+  const double* q = tile + (s * ti) * Wp + tj;
+  double acc = 0.0;
+#pragma unroll 4
+  for (int t = 0; t < ntaps; ++t) {
+    const double2 tp = s_tap[t];
+    acc = fma(tp.x, q[(int)__double_as_longlong(tp.y)], acc);
+  }
+  const int oy = oy0 + ti, ox = ox0 + tj;
+  if (oy < So && ox < So) {
+    const int64_t o = (int64_t)plane * So * So + (int64_t)oy * So + ox;
+    if (add != nullptr) acc = fma(add_scale, add[o], acc);
+    out[o] = acc;
+  }
+}
+
+constexpr int kUpMaxPhases = 16;  // s <= 4
+
+__global__ __launch_bounds__(256) void k_conv_up(const double* __restrict__ in, double* __restrict__ out,
+                                                 const int* __restrict__ tdy, const int* __restrict__ tdx,
+                                                 const double* __restrict__ tw, int ntaps, int S, int s, int hy, int hx,
+                                                 int cap, const double* __restrict__ add, double add_scale,
+                                                 const fh_cg_state* __restrict__ states) {
+  IMG_GUARD(states, blockIdx.z / 3);
+  extern __shared__ __align__(16) double lds_up[];  // [s*s][cap] (weight, offset) | [Hu][Wu] tile of u | [16 s][16 s + 1] outputs
+  const int Sin = S / s, hqy = (hy + s - 1) / s, hqx = (hx + s - 1) / s;
+  const int Hu = 16 + 2 * hqy, Wu = 16 + 2 * hqx + 1, T = 16 * s, SW = T + 1;
+  double2* lists = reinterpret_cast<double2*>(lds_up);
+  double* utile = lds_up + 2 * s * s * cap;
+  double* stage = utile + ((Hu * Wu + 1) & ~1);
+  __shared__ int cnt_s[kUpMaxPhases];
+  const int plane = blockIdx.z, tid = threadIdx.x;
+  const double* src = in + (int64_t)plane * Sin * Sin;
+  const int a0 = blockIdx.y * 16 - hqy, b0 = blockIdx.x * 16 - hqx;
+  for (int idx = tid; idx < Hu * (Wu - 1); idx += 256) {
+    const int r = idx / (Wu - 1), c = idx % (Wu - 1);
+    int ga = (a0 + r) % Sin, gb = (b0 + c) % Sin;
+    ga += ga < 0 ? Sin : 0;
+    gb += gb < 0 ? Sin : 0;
+    utile[r * Wu + c] = src[(int64_t)ga * Sin + gb];
+  }
+  if (tid < 64) {  // one wave sorts the taps by phase, keeping the list order inside every phase
+    const int lane = tid;
+    int cnt[kUpMaxPhases];
+#pragma unroll
+    for (int p = 0; p < kUpMaxPhases; ++p) cnt[p] = 0;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int t0 = 0; t0 < ntaps; t0 += 64) {
+      const int t = t0 + lane;
+      const bool valid = t < ntaps;
+      const int dy = valid ? tdy[t] : 0, dx = valid ? tdx[t] : 0;
+      const int py = ((-dy) % s + s) % s, px = ((-dx) % s + s) % s;
+      const int ph = valid ? py * s + px : -1;
+      const double2 item = make_double2(valid ? tw[t] : 0.0,
+                                        __longlong_as_double((long long)(((py + dy) / s) * Wu + (px + dx) / s)));
+#pragma unroll
+      for (int p = 0; p < kUpMaxPhases; ++p) {
+        const unsigned long long mask = __ballot(ph == p);
+        if (ph == p) {
+          const int pos = cnt[p] + __popcll(mask & lt);
+          if (pos < cap) lists[p * cap + pos] = item;
+        }
+        cnt[p] += __popcll(mask);
+      }
+    }
+    if (lane < kUpMaxPhases) {
+      int c = 0;
+#pragma unroll
+      for (int p = 0; p < kUpMaxPhases; ++p) c = lane == p ? cnt[p] : c;
+      cnt_s[lane] = c < cap ? c : cap;
+    }
+  }
+  __syncthreads();
+  const int la = tid >> 4, lb = tid & 15;
+  const double* q = utile + (la + hqy) * Wu + lb + hqx;
+  for (int p = 0; p < s * s; ++p) {
+    const int n = cnt_s[p];
+    const double2* lp = lists + p * cap;
+    double acc = 0.0;
+    for (int t = 0; t < n; ++t) {
+      const double2 tp = lp[t];
+      acc = fma(tp.x, q[(int)__double_as_longlong(tp.y)], acc);
+    }
+    stage[(s * la + p / s) * SW + s * lb + p % s] = acc;
+  }
+  __syncthreads();
+  const int oy0 = blockIdx.y * T, ox0 = blockIdx.x * T;
+  for (int idx = tid; idx < T * T; idx += 256) {
+    const int r = idx / T, c = idx % T;
+    const int oy = oy0 + r, ox = ox0 + c;
+    if (oy < S && ox < S) {
+      const int64_t o = (int64_t)plane * S * S + (int64_t)oy * S + ox;
+      double v = stage[r * SW + c];
+      if (add != nullptr) v = fma(add_scale, add[o], v);
+      out[o] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The m x m part of a Woodbury step / forward time shift on the device (online_update_bfgs.py:87-119 in the real form of
 // this build):   Mdst = sym( sign * Msrc (I + alpha G Msrc)^-1 ),   (alpha, sign) = (1, -1): Woodbury inverse; (s, +1): shift.
 // One workgroup, matrices in LDS.  A = I + alpha G Msrc is NOT well conditioned: the factor columns of a trajectory are
@@ -1656,6 +1795,40 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
     halo = hy2 > hx2 ? hy2 : hx2;
   }
   if (stride < 1 || S % stride != 0 || halo < -133 || halo > 32 || ntaps > kMaxTaps) return FH_EINVAL;
+  if (stride > 1 && stride <= 4 && halo >= 0) {  // SR pair on the LDS-tiled kernels when the sizes allow
+    const int hyq = hy2 >= 0 ? hy2 : halo, hxq = hy2 >= 0 ? hx2 : halo, s_ = stride;
+    static bool attr_sr = false;
+    if (!attr_sr) {
+      FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_dec), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   100 * 1024));
+      FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_up), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   100 * 1024));
+      attr_sr = true;
+    }
+    if (!adjoint && (S / s_) % 16 == 0) {
+      const int hq = (hxq + s_ - 1) / s_, R = 15 * s_ + 1 + 2 * hyq, Wp = 16 + 2 * hq + 1;
+      const size_t lds = (((size_t)s_ * R * Wp + 1) & ~(size_t)1) * sizeof(double) + (size_t)ntaps * 16;
+      if (lds <= 100 * 1024) {
+        const int So = S / s_;
+        hipLaunchKernelGGL(k_conv_dec, dim3(So / 16, So / 16, planes), dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, s_,
+                           hyq, hxq, add, add_scale, done);
+        FH_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    if (adjoint && S % (16 * s_) == 0) {
+      const int hqy = (hyq + s_ - 1) / s_, hqx = (hxq + s_ - 1) / s_;
+      const int cap = ((2 * hyq + s_) / s_ + 1) * ((2 * hxq + s_) / s_ + 1);  // >= taps of one phase
+      const int Hu = 16 + 2 * hqy, Wu = 16 + 2 * hqx + 1, T = 16 * s_;
+      const size_t lds = ((size_t)2 * s_ * s_ * cap + (((size_t)Hu * Wu + 1) & ~(size_t)1) + (size_t)T * (T + 1)) * sizeof(double);
+      if (lds <= 100 * 1024) {
+        hipLaunchKernelGGL(k_conv_up, dim3(S / T, S / T, planes), dim3(256), lds, st, in, out, dy, dx, w, ntaps, S, s_, hyq,
+                           hxq, cap, add, add_scale, done);
+        FH_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   if (!adjoint && stride > 1) {
     const int So = S / stride;
     const int64_t total = (int64_t)planes * So * So;
