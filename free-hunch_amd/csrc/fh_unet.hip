@@ -212,7 +212,9 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r;
 }
 
-// NP = 3: the exact split above (six products).  NP = 1: plain bf16 compute - operands rounded to bf16 (plane 0 = rn(x)),
+// NP = 3: the exact split above (six products).  NP = 2: the two leading planes, three products (h h' + h m' + m h'):
+// operands carried to 2^-17, product terms below 2^-16 dropped - between TF32 (2^-11, the default convolution arithmetic of
+// the reference's CUDA path) and fp32.  NP = 1: plain bf16 compute - operands rounded to bf16 (plane 0 = rn(x)),
 // one product, fp32 accumulation: the reduced-precision mode of the UNet (fh_unet_set_precision; NOT an fp32-parity mode).
 template <int MI, int NI, int WM, int WN, int MINW, int NP = 3>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
 __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
@@ -307,10 +309,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
-      if (NP == 3) {
-        *reinterpret_cast<bf16x4_t*>(&As[NP - 2][a_row[e]][a_c4]) = m4;
-        *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
-      }
+      if (NP >= 2) *reinterpret_cast<bf16x4_t*>(&As[NP >= 2 ? 1 : 0][a_row[e]][a_c4]) = m4;
+      if (NP == 3) *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
     }
 #pragma unroll
     for (int e = 0; e < IB; ++e)
@@ -342,12 +342,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         float16_t t = acc[i][j];
-        if (NP == 3) {
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bfr[0][j], t, 0, 0, 0);       // l h'
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 1][j], t, 0, 0, 0);       // h l'
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[NP - 2][j], t, 0, 0, 0);  // m m'
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[0][j], t, 0, 0, 0);       // m h'
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 2][j], t, 0, 0, 0);       // h m'
+        if (NP == 3) {  // smallest terms first: l h', h l', m m'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bfr[0][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 1][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
+        }
+        if (NP >= 2) {  // m h', h m'
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
         }
         t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);  // h h'
         acc[i][j] = t;
@@ -505,10 +507,8 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
-      if (NP == 3) {
-        *reinterpret_cast<bf16x4_t*>(&As[NP - 2][a_row[e]][a_c4]) = m4;
-        *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
-      }
+      if (NP >= 2) *reinterpret_cast<bf16x4_t*>(&As[NP >= 2 ? 1 : 0][a_row[e]][a_c4]) = m4;
+      if (NP == 3) *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
     }
   };
   auto store_b = [&](int buf) {
@@ -543,12 +543,14 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           float16_t t = acc[i][j];
-          if (NP == 3) {
+          if (NP == 3) {  // smallest terms first: l h', h l', m m'
             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1][i], bfr[0][j], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 1][j], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[NP - 2][j], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 2][i], bfr[0][j], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP - 2][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
+          }
+          if (NP >= 2) {  // m h', h m'
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
           }
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);
           acc[i][j] = t;
@@ -1260,16 +1262,19 @@ extern "C" {
 // (operands rounded to bf16, one product, fp32 accumulation) - the reduced-precision UNet mode, the counterpart of the
 // reference's use_fp16 torso (training/openai_fp16_util.py:15-32).  Process-wide: set before a forward / VJP.
 static int g_conv_np = 3;
-#define X6_DISPATCH(K1, K3, ...)                     \
+#define X6_DISPATCH(K1, K2, K3, ...)                 \
   do {                                               \
     if (g_conv_np == 1)                              \
       hipLaunchKernelGGL(K1, __VA_ARGS__);           \
+    else if (g_conv_np == 2)                         \
+      hipLaunchKernelGGL(K2, __VA_ARGS__);           \
     else                                             \
       hipLaunchKernelGGL(K3, __VA_ARGS__);           \
   } while (0)
 
-int fh_unet_set_precision(int bf16_compute) {
-  g_conv_np = bf16_compute ? 1 : 3;
+int fh_unet_set_precision(int mode) {
+  if (mode < 0 || mode > 2) return FH_EINVAL;
+  g_conv_np = mode == 0 ? 3 : (mode == 1 ? 1 : 2);
   return 0;
 }
 
@@ -1341,26 +1346,26 @@ int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const 
     const bool big = r3 && !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
     if (big && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 2>), (k_conv_x6r<64, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (r3 && W % 128 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 2>), (k_conv_x6r<128, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 64 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 2>), (k_conv_x6r<64, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 32 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 2>), (k_conv_x6r<32, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else
-      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
   } else if (ksplit > 1 && Cout > 64 && b128 * ksplit >= 256 && !getenv("FH_X6_NOBIGSPLIT")) {
     // small grids: 128 x 128 tiles (21 flop per byte pulled from L2 instead of 12.8) once split-K still fills the chip
-    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
-    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 2>), (k_conv_x6<1, 2, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
-    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 2>), (k_conv_x6<1, 1, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
   }
   if (ksplit > 1) {
     const int64_t total = M * Cout;
@@ -1421,17 +1426,17 @@ int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, cons
   const bool big = !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
   if (big && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 2>), (k_conv_x6r<64, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (W % 128 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 2>), (k_conv_x6r<128, true, 128, 3>), grid, dim3(512), 0, st, a);
   else if (W == 64)
-    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 2>), (k_conv_x6r<64, true, 128, 3>), grid, dim3(512), 0, st, a);
   else
-    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 2>), (k_conv_x6r<32, true, 128, 3>), grid, dim3(512), 0, st, a);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -21,6 +21,9 @@ import torch
 import torch.nn.functional as F
 
 
+_PRECISION_MODE = {"fp32": 0, "bf16": 1, "bf16x3": 2}  # fh_unet_set_precision codes
+
+
 @dataclass
 class UNetConfig:
     image_size: int = 256
@@ -263,18 +266,21 @@ class UNetModel(torch.nn.Module):
         "bf16": reduced-precision torso - convolution operands rounded to bf16, fp32 accumulation, everything else
         (GroupNorm, attention, residuals, storage) stays fp32.  This is the counterpart of the reference's `use_fp16` torso
         (training/openai_fp16_util.py:15-32); "fp16" is accepted as an alias: gfx950 runs bf16 and fp16 MFMAs at the same
-        rate and bf16 keeps the fp32 exponent range.  Outside the fp32 parity bar - reported as a separate mode."""
+        rate and bf16 keeps the fp32 exponent range.  Outside the fp32 parity bar - reported as a separate mode.
+        "bf16x3": operands carried as two bf16 planes, three matrix products per convolution (relative error ~ 2^-16, i.e.
+        between TF32 - what the reference's convolutions run in by default on its CUDA path - and fp32) at half the
+        matrix work of "fp32".  Also reported separately."""
         if dtype == "fp16":
             import warnings
             warnings.warn("unet dtype fp16 -> bf16 compute (same MFMA rate on gfx950, fp32 exponent range)")
             dtype = "bf16"
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError(f"unet dtype must be fp32, bf16 or fp16, got {dtype}")
+        if dtype not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError(f"unet dtype must be fp32, bf16x3, bf16 or fp16, got {dtype}")
         if dtype != "fp32" and self.backend != "hip":
             raise NotImplementedError("the reduced-precision torso exists on the hip backend only")
         self.dtype_mode = dtype
         if getattr(self, "_ops", None) is not None and hasattr(self._ops, "bf16"):
-            self._ops.bf16 = dtype == "bf16"
+            self._ops.bf16 = _PRECISION_MODE[dtype]
         return self
 
     # the reference's key names in and out ------------------------------------------------------------
@@ -306,7 +312,7 @@ class UNetModel(torch.nn.Module):
             elif self.backend == "hip":
                 from .unet_hip import HipOps
                 self._ops = HipOps(self.cfg, self._params())
-                self._ops.bf16 = self.dtype_mode == "bf16"
+                self._ops.bf16 = _PRECISION_MODE[self.dtype_mode]
             else:
                 raise ValueError(f"unknown backend {self.backend}")
         return self._ops

@@ -267,8 +267,10 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
 /* Precision of the convolution kernels that run on the bf16 matrix cores (fh_conv2d_x6_nhwc, fh_conv2d_x6_norm_nhwc):
  * 0 (default) = exact 3-way operand split, fp32 accuracy; 1 = plain bf16 compute (operands rounded to bf16, one product,
  * fp32 accumulation) - the reduced-precision UNet mode, counterpart of the reference's fp16 torso
- * (training/openai_fp16_util.py:15-32, flag path openai_preconditioning.py:171).  Process-wide. */
-int fh_unet_set_precision(int bf16_compute);
+ * (training/openai_fp16_util.py:15-32, flag path openai_preconditioning.py:171); 2 = the two leading bf16 planes of both
+ * operands, three products (relative error ~ 2^-16: between TF32, the default convolution arithmetic of the reference's
+ * CUDA path, and fp32) - half the matrix work of mode 0.  Process-wide. */
+int fh_unet_set_precision(int mode);
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 
 /* Same convolution as fh_conv2d_nhwc at fp32 accuracy on the bf16 matrix cores: operands are split exactly into three

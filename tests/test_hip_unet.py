@@ -415,7 +415,7 @@ def test_unet_bf16_mode_vs_fp32(dev):
     t = torch.tensor([300, 300], device=dev)
     cot = inputs.randn((2, 6, 256, 256), 19, torch.float32).to(dev)
     outs = []
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16", "bf16x3"):
         m = hu.UNetModel(cfg, backend="hip", dtype=dtype)
         m.load_state_dict(sd)
         m = m.to(dev).eval()
@@ -427,6 +427,12 @@ def test_unet_bf16_mode_vs_fp32(dev):
     ey, eg = rel(outs[1][0], outs[0][0]), rel(outs[1][1], outs[0][1])
     assert 1e-5 < ey < 5e-2, ey
     assert 1e-5 < eg < 1e-1, eg
+    # "bf16x3" (two bf16 planes per operand, three products): ~ 2^-16 per product - two orders below the bf16 mode, inside the
+    # north star's 1e-3 max-abs bar on the network output, but not fp32: reported as its own mode
+    ey3, eg3 = rel(outs[2][0], outs[0][0]), rel(outs[2][1], outs[0][1])
+    assert 1e-8 < ey3 < 1e-4 and ey3 < ey / 30, (ey3, ey)
+    assert 1e-8 < eg3 < 3e-4 and eg3 < eg / 30, (eg3, eg)
+    assert float((outs[2][0] - outs[0][0]).abs().max()) < 1e-3
     # and the default is untouched by having run the reduced mode in the same process
     m = hu.UNetModel(cfg, backend="hip")
     m.load_state_dict(sd)
