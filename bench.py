@@ -149,14 +149,13 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 1e3 / iters
 
-    # What the samplers issue: their contexts are exclusive (nothing else synchronises across workgroups on the GPU), which
-    # selects the single-sweep kernel (k_rep_fused: B stays in registers between the reduction and the product) for
-    # single-image launches and the two-pass kernels for batched ones (the single sweep is slower there:
-    # profiles/r02_cov_apply_single_sweep.md).  The other variant is timed beside it.
+    # What the samplers issue: the two-pass kernels (k_rep_dots + k_rep_coef + k_rep_apply2).  The single-sweep kernel
+    # (k_rep_fused: B stays in registers between the reduction and the product; opt-in, fh_context_set_exclusive(ctx, 2)) is
+    # timed beside it - bitwise equal, read-once traffic, but not faster (profiles/r02_cov_apply_single_sweep.md).
     ctx.set_exclusive(1)
     sec = timed()
     ctx.status()
-    ctx.set_exclusive(0 if nimg == 1 else 2)
+    ctx.set_exclusive(2)
     sec_alt = timed()
     ctx.status()
     ctx.set_exclusive(0)
@@ -166,14 +165,16 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
     pmc = os.path.join(ROOT, "profiles", "r02_cov_apply_pmc.json" if nimg == 1 else "r02_cov_apply_b8_pmc.json")
     if m == 32 and nimg in (1, 8) and os.path.exists(pmc):
         with open(pmc) as f_:
-            traffic = json.load(f_).get("traffic_bytes_per_apply")
+            rec = json.load(f_)
+        # the one-image file holds the single-sweep kernel's counters, the two-pass ones under "two_pass_for_comparison"
+        traffic = (rec.get("two_pass_for_comparison", {}) if nimg == 1 else rec).get("traffic_bytes_per_apply")
     two_pass, fused = "k_rep_dots + k_rep_coef + k_rep_apply2 (two sweeps of B)", "k_rep_fused<4> (single sweep: B read once)"
-    return {"bound": "hbm", "kernel": f"fh_rep_apply = {fused if nimg == 1 else two_pass}; d=196608, m={m}, f64, "
+    return {"bound": "hbm", "kernel": f"fh_rep_apply = {two_pass}; d=196608, m={m}, f64, "
                                       f"{nimg} image{'s' if nimg > 1 else ''} per launch",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2),
-            "other_variant": {"kernel": two_pass if nimg == 1 else fused,
+            "other_variant": {"kernel": fused,
                               "achieved": round(algo_bytes / sec_alt / 1e9, 1), "unit": "GB/s",
                               "frac": round(algo_bytes / sec_alt / 1e9 / HBM_PEAK_GBS, 4),
                               "us_per_apply": round(sec_alt * 1e6, 2)}}

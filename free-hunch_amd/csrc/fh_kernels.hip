@@ -558,6 +558,10 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
   for (int w8 = 0; w8 < 8; ++w8)
 #pragma unroll
     for (int q = 0; q < kR; ++q) ch[w8][q] = 0.0;
+  // the three per-row vectors are requested before the base: their latency hides behind the sweep instead of its tail
+  double zq[kR], dq[kR], rq[kR];
+#pragma unroll
+  for (int q = 0; q < kR; ++q) zq[q] = z[row[q]], dq[q] = D[row[q]], rq[q] = m > 0 ? r[row[q]] : 0.0;
   const int mfull = m & ~7;
   for (int j0 = 0; j0 < mfull; j0 += 8) {  // 24 independent streaming loads per step
     double b[8][kR];
@@ -586,8 +590,7 @@ __global__ __launch_bounds__(256) void k_rep_apply2(fh_batch per, const double* 
     double acc = ch[0][q];
 #pragma unroll
     for (int w8 = 1; w8 < 8; ++w8) acc += ch[w8][q];
-    const double zz = z[row[q]], dd = D[row[q]];
-    const double o = m > 0 ? fma(r[row[q]], acc, dd * zz) : dd * zz;
+    const double o = m > 0 ? fma(rq[q], acc, dq[q] * zq[q]) : dq[q] * zq[q];
     if (ok[q]) out[row[q]] = o;
   }
 }
@@ -824,12 +827,13 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
   // TB/s): same order 2.75, reverse order 2.97; splitting the batch into cache-sized groups of 4 (each group both
   // passes back to back) 2.80 - the extra dependent launches cost more than the additional hits return.
   const unsigned Z = (unsigned)per.nimg;
-  // Single-sweep kernel: one image per launch on an exclusive context.  (Several images per launch are correct - the test
-  // suite runs them with fh_context_set_exclusive(ctx, 2) - but slower than the two-pass kernels: the hand-off of one image goes through
-  // the same per-CU memory queues as the next image's streaming loads and stretches from 13 us to 19 us, see
-  // profiles/r02_cov_apply_single_sweep.md.)
-  if (out != nullptr && m > 0 && m <= 64 && ctx->exclusive && !ctx->fused_disabled && d % kDotRows == 0 && nb <= ctx->num_cus &&
-      nb <= 256 && (per.nimg == 1 || ctx->exclusive >= 2)) {
+  // Single-sweep kernel: only on explicit request (fh_context_set_exclusive(ctx, 2): tests, profiling).  It reads the base once
+  // and is bitwise equal, but since the two sweeps run at the per-CU ingest limit it is no longer faster anywhere: one image
+  // per launch 26.0-27.0 us vs 25.5 us, eight images 161-177 us vs 139.5 us (the hand-off of one image goes through the same
+  // per-CU memory queues as the next image's streaming loads and stretches from 13 us to 19 us, see
+  // profiles/r02_cov_apply_single_sweep.md).
+  if (out != nullptr && m > 0 && m <= 64 && ctx->exclusive >= 2 && !ctx->fused_disabled && d % kDotRows == 0 &&
+      nb <= ctx->num_cus && nb <= 256) {
     unsigned long long* dbg = getenv("FH_FUSED_DEBUG") ? (unsigned long long*)ctx->gpartial : nullptr;  // profiling only
     if (m <= 32)
       hipLaunchKernelGGL((k_rep_fused<4>), dim3(nb, 1, Z), dim3(512), 0, st, per, z, out, ctx->partial, ctx->sync, d, m, ldm,

@@ -83,7 +83,7 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
     cov_ctx = getattr(getattr(mech, "covariance_model", None), "ctx", None)
     if cov_ctx is not None:
         # one image, one stream: no other grid-synchronising kernel can share the GPU with this image's Free Hunch work,
-        # so the covariance apply may keep the factor base on chip (include/fh_hip.h: fh_context_set_exclusive)
+        # (include/fh_hip.h: fh_context_set_exclusive; level 1 declares it, level 2 would select the single-sweep apply)
         cov_ctx.set_exclusive(other_args.get("exclusive_device", True))
     y = cond_images.to(noise.device)
     f64 = lambda v: torch.tensor(v, dtype=torch.float64, device=noise.device)

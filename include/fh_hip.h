@@ -38,13 +38,13 @@ int fh_version(void);
 /* S = image side (<= 256), planes_max = largest planes count that will be passed, m_cap = column capacity */
 int fh_context_create(fh_context** out, int S, int planes_max, int m_cap);
 int fh_context_destroy(fh_context* ctx);
-/* exclusive = 1: the caller guarantees that kernels of this context never run concurrently with another
+/* exclusive >= 1: the caller guarantees that kernels of this context never run concurrently with another
  * grid-synchronising kernel on the same GPU (one FH stream per process, e.g. the single-image sampler or the lock-step
- * batched CG).  The covariance apply (fh_rep_apply[_batched], and inside fh_cg_solve[_batched] / fh_amm / the covariance
- * updates) then takes the single-sweep kernel that keeps the factor base in registers between the reduction and the
- * product (B read once instead of twice) for single-image launches; exclusive = 2 extends that to batched launches
- * (correct, but measured slower than the two-pass kernels - kept for the tests and for profiling).  Default 0: two-pass
- * kernels, safe under any concurrency.  Results are bitwise identical in all modes. */
+ * batched CG).  exclusive = 2 additionally selects the single-sweep covariance apply (fh_rep_apply[_batched], and inside
+ * fh_cg_solve[_batched] / fh_amm): one launch that keeps the factor base in registers between the reduction and the
+ * product (B read once instead of twice).  It is bitwise identical to the two-pass kernels and, since those run at the
+ * per-CU ingest limit, no longer faster for any launch shape (profiles/r02_cov_apply_single_sweep.md) - kept for the tests
+ * and for profiling.  Default 0, and 1: two-pass kernels, safe under any concurrency. */
 int fh_context_set_exclusive(fh_context* ctx, int exclusive);
 /* 0, or FH_ESYNC if a single-sweep apply of this context timed out waiting for its peer workgroups since the last call
  * (its output was invalid; the context then stays on the two-pass kernels).  Synchronises the stream. */
