@@ -2,7 +2,7 @@
 # HBM-side traffic (FETCH_SIZE, WRITE_SIZE in separate --pmc passes) and kernel times of the cov-apply at d = 196608, m = 32
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_cov; rm -rf $O; mkdir -p $O
-for cfg in "8 0 b8_twopass" "1 1 b1_singlesweep" "1 0 b1_twopass"; do
+for cfg in "8 0 b8_twopass" "1 2 b1_singlesweep" "1 0 b1_twopass"; do
   set -- $cfg
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/$3_stats -- python3 profiles/tools/prof_cov_one.py $1 $2 > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$3_fetch -- python3 profiles/tools/prof_cov_one.py $1 $2 > /dev/null 2>&1
