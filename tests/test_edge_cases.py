@@ -194,3 +194,51 @@ def test_batched_cg_with_a_finished_image(dev, tmp_path):
         assert infos[i].niter == singles[i][1] and infos[i].optimal == singles[i][2], (i, infos[i].niter, singles[i][1])
         assert float((sol[i] - singles[i][0]).abs().max()) <= 1e-12 * max(1.0, float(singles[i][0].abs().max())), i
     assert infos[1].niter == 1 and not infos[1].optimal
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,stride,kh,kw,density", [
+    (64, 1, 9, 5, 0.5),     # k_conv_tile8, one 64 x 32 tile per row block
+    (96, 1, 31, 7, 0.3),    # partial tiles in both directions, tall sparse PSF
+    (256, 1, 61, 17, 0.2),  # the motion PSF's extent
+    (64, 1, 61, 61, 0.1),   # halo beyond the LDS budget of the 8-output kernel: k_conv_tile
+    (64, 2, 7, 7, 1.0),     # k_conv_dec / k_conv_up at every stride the reference's SR kernels cover
+    (96, 3, 11, 9, 1.0),
+    (64, 4, 25, 25, 1.0),
+    (256, 4, 25, 25, 1.0),
+    (48, 4, 25, 25, 1.0),   # sizes the tiled SR kernels do not take: k_conv_direct / k_conv_tile
+])
+def test_conv_circ_matches_a_direct_sum(S, stride, kh, kw, density):
+    """fh_conv_circ over every kernel it dispatches to (k_conv_tile8, k_conv_tile, k_conv_dec, k_conv_up, k_conv_direct)
+    against the defining circular sums in NumPy, forward and adjoint, random non-symmetric tap sets:
+      forward  out[i][j] = sum_t w_t in[(s i - dy_t) mod S][(s j - dx_t) mod S]
+      adjoint  out[y][x] = sum_t w_t z[(y + dy_t) mod S][(x + dx_t) mod S],  z = in with s - 1 zeros inserted
+    and <A x, y> = <x, A^T y> to rounding."""
+    import numpy as np
+    from free_hunch_amd import _lib
+    from free_hunch_amd.measurements import _TapList
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(S * 131 + stride * 17 + kh)
+    k = rng.standard_normal((kh, kw)) * (rng.random((kh, kw)) < density)
+    k[0, 0], k[-1, -1] = 0.7, -0.4  # the full extent is always populated
+    taps = _TapList(k, dev)
+    ctx = _lib.Context.get(S, 3, 0)
+    So = S // stride
+    x = rng.standard_normal((3, S, S))
+    u = rng.standard_normal((3, So, So))
+    dy, dx, w = taps.dy.cpu().numpy(), taps.dx.cpu().numpy(), taps.w.cpu().numpy()
+    fwd = np.zeros((3, So, So))
+    zi = np.zeros((3, S, S))
+    zi[:, ::stride, ::stride] = u
+    adj = np.zeros((3, S, S))
+    for t in range(taps.n):
+        fwd += w[t] * np.roll(x, (dy[t], dx[t]), axis=(1, 2))[:, ::stride, ::stride]
+        adj += w[t] * np.roll(zi, (-dy[t], -dx[t]), axis=(1, 2))
+    xd, ud = torch.from_numpy(x).to(dev), torch.from_numpy(u).to(dev)
+    got_f = ctx.conv(xd, torch.empty(3, So, So, dtype=torch.float64, device=dev), taps, 3, stride, False)
+    got_a = ctx.conv(ud, torch.empty(3, S, S, dtype=torch.float64, device=dev), taps, 3, stride, True)
+    torch.cuda.synchronize()
+    assert np.abs(got_f.cpu().numpy() - fwd).max() < 1e-12 * max(1.0, np.abs(fwd).max())
+    assert np.abs(got_a.cpu().numpy() - adj).max() < 1e-12 * max(1.0, np.abs(adj).max())
+    lhs, rhs = float((got_f * ud).sum()), float((xd * got_a).sum())
+    assert abs(lhs - rhs) < 1e-10 * max(1.0, abs(lhs))
