@@ -1523,6 +1523,7 @@ __global__ __launch_bounds__(256) void k_conv_up(const double* __restrict__ in, 
 // ------------------------------------------------------------------------------------------------
 constexpr int kWbMax = 64;
 constexpr int kWbRefine = 12;
+constexpr int kWbLdsMax = 48;  // (m (2m+1) + 2 m (m+1) + 3 m^2) doubles = 129 KB at m = 48
 
 struct dd_acc {
   double hi, lo;
@@ -1549,9 +1550,11 @@ __global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict
   double* aug = wb;                 // [m][w]   left: A^T, later X;  right: I, later A^-T
   double* Ms = wb + m * w;          // [m][m+1] Msrc
   double* Gs = Ms + m * q;          // [m][m+1] alpha G
-  double* Ahi = scratch;            // [m][m]
-  double* Alo = scratch + m * m;
-  double* Rs = scratch + 2 * m * m;
+  // A (hi / lo) and the residual live in LDS while they fit beside the elimination (m <= kWbLdsMax), else in the scratch
+  double* extra = Gs + m * q;
+  double* Ahi = m <= kWbLdsMax ? extra : scratch;  // [m][m]
+  double* Alo = m <= kWbLdsMax ? extra + m * m : scratch + m * m;
+  double* Rs = m <= kWbLdsMax ? extra + 2 * m * m : scratch + 2 * m * m;
   double* Dl = scratch + 3 * m * m;  // the last applied correction
   __shared__ int piv;
   __shared__ double pval;
@@ -2344,7 +2347,7 @@ static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const d
   if (!ctx || m < 0 || (m > 0 && (!Msrc || !G || !Mdst || ld_src < m || ldg < m || ld_dst < m))) return FH_EINVAL;
   if (m == 0) return 0;
   if (m > kWbMax) return FH_ESIZE;  // the caller falls back to its host path
-  const size_t lds = ((size_t)m * (2 * m + 1) + 2 * (size_t)m * (m + 1)) * sizeof(double);
+  const size_t lds = ((size_t)m * (2 * m + 1) + 2 * (size_t)m * (m + 1) + (m <= kWbLdsMax ? 3 * (size_t)m * m : 0)) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     FH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_woodbury_inner),
