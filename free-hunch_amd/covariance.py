@@ -144,6 +144,8 @@ class CovarianceHessianBFGS:
         self._G = torch.zeros(m_cap, m_cap, dtype=F64, device=self.device)
         self._scal = torch.zeros(8, dtype=F64, device=self.device)
         self._t0, self._t1, self._t2 = (torch.empty(d, dtype=F64, device=self.device) for _ in range(3))
+        self._tu0, self._tu1 = (torch.empty(d, dtype=F64, device=self.device) for _ in range(2))  # time-update work vectors
+        self._st_cache = None
         # `0 < max_vector_count`: the reference keeps "the newest columns" of its sqrtm-mixed factors (:240-244), so those
         # factors must exist.  They are tracked in base coordinates (m x k complex matrices QU, QV per representation of
         # the C family - host algebra on a few dozen numbers, the d-sized work stays in the kernels); a count that the
@@ -172,6 +174,7 @@ class CovarianceHessianBFGS:
             rep.grow(cap)
         self._G = torch.zeros(cap, cap, dtype=F64, device=self.device)
         self.m_cap = cap
+        self._st_cache = None
 
     def _invert(self, src, dst, fam, shift=0.0):
         """dst <- (src + shift*I)^-1 over the family's base; src.D is shifted in place.  No host round trip for
@@ -221,14 +224,23 @@ class CovarianceHessianBFGS:
         return 0.5 * (M + M.T)
 
     def _state(self):
-        st = _lib.FhCovState()
-        st.d, st.m_c, st.m_h = self.data_dim, self.famC.m, self.famH.m
-        st.ldm, st.ldg = self.C.M_dev.shape[1], self._G.shape[1]
-        st.project, st.use_dct = int(bool(self.project_to_diagonal)), int(self.use_dct)
-        for i, rep in enumerate((self.C, self.Ci, self.H, self.Hi)):
-            st.D[i], st.r[i], st.M[i] = rep.D.data_ptr(), rep.r.data_ptr(), rep.M_dev.data_ptr()
-        st.Bc, st.Bh, st.G, st.scal = self.famC.B.data_ptr(), self.famH.B.data_ptr(), self._G.data_ptr(), self._scal.data_ptr()
-        st.t0, st.t1, st.t2 = self._t0.data_ptr(), self._t1.data_ptr(), self._t2.data_ptr()
+        """the fh_cov_state of this object.  The pointer part is cached: the tensors behind it are replaced only when the
+        column capacity grows (`_ensure_capacity` drops the cache); building it costs ~ 30 us of host time, and the
+        lock-step sampler's update phase is bound by exactly that kind of per-image host work."""
+        st = self._st_cache
+        if st is None:
+            st = _lib.FhCovState()
+            st.d = self.data_dim
+            st.ldm, st.ldg = self.C.M_dev.shape[1], self._G.shape[1]
+            st.use_dct = int(self.use_dct)
+            for i, rep in enumerate((self.C, self.Ci, self.H, self.Hi)):
+                st.D[i], st.r[i], st.M[i] = rep.D.data_ptr(), rep.r.data_ptr(), rep.M_dev.data_ptr()
+            st.Bc, st.Bh, st.G, st.scal = (self.famC.B.data_ptr(), self.famH.B.data_ptr(), self._G.data_ptr(),
+                                           self._scal.data_ptr())
+            st.t0, st.t1, st.t2 = self._t0.data_ptr(), self._t1.data_ptr(), self._t2.data_ptr()
+            self._st_cache = st
+        st.m_c, st.m_h = self.famC.m, self.famH.m
+        st.project = int(bool(self.project_to_diagonal))
         return st
 
     def _apply(self, rep, fam, z, out):
@@ -249,6 +261,13 @@ class CovarianceHessianBFGS:
 
     def _vec(self, x):
         return x.detach().to(device=self.device, dtype=F64).reshape(-1).contiguous()
+
+    def _raw(self, x):
+        """x itself when it already is a contiguous float64 tensor on this device (only its pointer is needed by the
+        one-call updates), else the converted copy.  Four dispatcher calls per vector add up in the lock-step sampler."""
+        if x.dtype is F64 and x.device == self.device and x.is_contiguous():
+            return x
+        return self._vec(x)
 
     def transform(self, x):
         return x
@@ -305,15 +324,15 @@ class CovarianceHessianBFGS:
         if max(self.famC.m, self.famH.m) <= 64 and os.environ.get("FH_COV_STEPWISE") != "1" and not self._track:
             # one C call enqueues the whole update (same kernels, same order as the step-by-step path below)
             ctx = self.ctx
-            x = self._vec(x_t)
             if only_covariance:
                 _lib.check(ctx.lib.fh_cov_time_update(ctx.h, C.byref(self._state()), None, None, shift_c, shift_h, 0.0, 1,
                                                       None, None, None, None, _lib.stream()), "fh_cov_time_update")
                 self.C.m = self.famC.m
                 x = x_t.detach().to(device=self.device, dtype=F64)
                 return x.clone(), x.clone()
-            sc = self._vec(score_t)
-            wx, ws, mean, score = (torch.empty_like(x) for _ in range(4))
+            x, sc = self._raw(x_t), self._raw(score_t)  # locals keep converted copies alive until the launch
+            wx, ws = self._tu0, self._tu1
+            mean, score = (torch.empty(self.data_dim, dtype=F64, device=self.device) for _ in range(2))
             _lib.check(ctx.lib.fh_cov_time_update(ctx.h, C.byref(self._state()), _lib.ptr(x), _lib.ptr(sc), shift_c, shift_h,
                                                   sigma_tnext ** 2, 0, _lib.ptr(wx), _lib.ptr(ws), _lib.ptr(mean),
                                                   _lib.ptr(score), _lib.stream()), "fh_cov_time_update")
@@ -348,7 +367,7 @@ class CovarianceHessianBFGS:
             self._ensure_capacity(max(mc if project else mc + 2, mh + 2))
             # locals keep the (possibly converted) inputs alive until the launch: a temporary freed between two
             # `_vec` calls would hand the same cached block to the next one
-            mx, mxn, vx, vxn = (self._vec(t) for t in (denoiser_mean_at_x, denoiser_mean_at_xnext, x, xnext))
+            mx, mxn, vx, vxn = (self._raw(t) for t in (denoiser_mean_at_x, denoiser_mean_at_xnext, x, xnext))
             _lib.check(lib.fh_cov_space_update(ctx.h, C.byref(self._state()), _lib.ptr(mx), _lib.ptr(mxn), s2,
                                                _lib.ptr(vx), _lib.ptr(vxn), _lib.stream()), "fh_cov_space_update")
             if not project:
