@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "fh_common.h"
@@ -2125,9 +2126,13 @@ extern "C" {
 
 int fh_version(void) { return 100; }
 
+// serialises hipGraph captures (cg_graph_for) against the legacy-stream work of context creation / destruction, see there
+static std::mutex g_capture_mu;
+
 int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   if (out == nullptr || S < 2 || S > 256 || (S & 1) || planes_max < 1 || m_cap < 0 || m_cap > FH_MAX_COLS)
     return FH_EINVAL;
+  std::lock_guard<std::mutex> capture_lock(g_capture_mu);
   fh_context* c = new fh_context();
   memset(c, 0, sizeof(*c));
   c->S = S;
@@ -2197,6 +2202,7 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
 
 int fh_context_destroy(fh_context* c) {
   if (c == nullptr) return 0;
+  std::lock_guard<std::mutex> capture_lock(g_capture_mu);
   void* bufs[] = {c->basis, c->basis_t, c->tmp_img, c->partial, c->gpartial, c->coef, c->cg_r,
                   c->cg_p,  c->cg_ap,   c->w0,      c->w1,      c->w2,       c->cg_state, c->sync,
                   c->sym_fwd, c->sym_inv};
@@ -2544,6 +2550,11 @@ static hipGraphExec_t cg_graph_for(fh_context* ctx, const fh_problem* p, const f
     (void)hipGraphDestroy(slot->graph);
     slot->exec = nullptr;
   }
+  // A capture is short (80 launches) but must not overlap, in another host thread of the process, with the legacy-stream
+  // copies and allocations of fh_context_create / fh_context_destroy (a second lock-step group creating its contexts):
+  // the capture is invalidated (hipErrorStreamCaptureInvalidated in this thread) or the other call fails
+  // (hipErrorStreamCaptureImplicit).  g_capture_mu serialises the two.
+  std::lock_guard<std::mutex> capture_lock(g_capture_mu);
   if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
     (void)hipGetLastError();
     ctx->graphs_disabled = 1;  // e.g. the legacy null stream: stay on eager launches
