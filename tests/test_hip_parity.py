@@ -383,10 +383,15 @@ def test_trajectory_free_running_vs_reference_golden(dev, gold, tag, unet, tmp_p
     assert maxabs(x, g[p + "x_final"]) < 1e-3  # north-star tolerance
 
 
+
 # every recorded configuration runs by default (the CPU-oracle side of the eleven cases costs ~4 min on the box's host)
 TF_TAGS = ["gb_heun10", "sr_heun10", "ip_euler20", "gb_heun10_identity", "sr_heun10+analytic", "sr_heun10+netscore"]
 if True:
     TF_TAGS += ["mb_heun10", "sr_heun10+project", "gb_heun10_nospace", "gb_heun10_readme", "ip_euler20+analytic"]
+# Heun-72 on the SR inputs: 37 BFGS pairs -> 74 factor columns.  Beyond 64 columns the covariance updates leave the one-call
+# kernels for the step-by-step path (Woodbury through the inverse representation, m x m solve on the host with
+# extended-precision refinement) and the CG applies run on the wide-column kernels
+TF_TAGS += ["sr_heun10+long72"]
 
 
 @pytest.mark.parametrize("tag", TF_TAGS)
@@ -403,6 +408,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     analytic = tag.endswith("+analytic")  # use_analytic_var_at_end = true (scalar-variance closed form below sigma 0.2)
     netscore = tag.endswith("+netscore")  # use_analytical_score_time_update = false (extra UNet call at x_prev, :252-254)
     project = tag.endswith("+project")    # project_to_diagonal = true (:274-277, incl. the Hessian quirk)
+    long72 = tag.endswith("+long72")
     tag = tag.split("+")[0]
     p = tag + "__"
     torch.save(T(g["dct_variance64"]), tmp_path / "dct_variance.pt")
@@ -424,6 +430,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     kw = _base_kwargs(tmp_path, over)
     _, onet = _cpu_oracle_net(dev)
     rows = []
+    probe = inputs.randn((1, 3, 64, 64), 97, torch.float64)
 
     class Pair:
         def __init__(self, op_, v0, d):
@@ -450,12 +457,20 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             rows.append(dict(sigma=float(sigma), no=to["niter"], nh=th["niter"], bo=to["branch"], bh=th["branch"],
                              ko=to["k"], kh=th["k"], err=maxabs(out_o, out_h), mag=float(out_o.abs().max()),
                              res=th["residual_norm"], rtol=th["rtol"], opt=th["optimal"]))
+            if long72:
+                co = self.o.cov.denoiser_cov_vector_dot(probe)
+                rows[-1]["probe"] = maxabs(co, self.h.covariance_model.denoiser_cov_vector_dot(probe.to(dev))) / float(co.abs().max())
             return out_o
 
-    fo.conditional_sampler(onet, noise, y, oop, num_steps=int(g[p + "num_steps"]), solver=str(g[p + "solver"]),
+    fo.conditional_sampler(onet, noise, y, oop, num_steps=72 if long72 else int(g[p + "num_steps"]), solver=str(g[p + "solver"]),
                            mechanism_factory=lambda op_, v0, d: Pair(op_, v0, d))
-    assert len(rows) == len(g[p + "niter"])
+    assert len(rows) == (143 if long72 else len(g[p + "niter"]))
+    if long72:
+        assert max(r["kh"] for r in rows) > 32, "the run must cross 64 factor columns"
     tight = loose = 0
+    if long72 and os.environ.get("FH_TEST_DUMP"):
+        for i, r in enumerate(rows):
+            print("ROW", i, {k_: (float(f"{v:.3g}") if isinstance(v, float) else v) for k_, v in r.items()}, flush=True)
     for r in rows:
         assert r["ko"] == r["kh"], r
         assert r["bo"] == r["bh"], r
@@ -463,6 +478,21 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
         if analytic and r["sigma"] < 0.2:
             assert rel < 1e-5, r  # closed form vs CG on the same system (iteration counts are not comparable)
             tight += 1
+        elif long72:
+            # With a random-weight UNet and 72 Heun steps the reference's covariance becomes INDEFINITE from the third pair on
+            # (its own CG stops after one iteration with p.Ap <= 1e-16 and returns estimates of magnitude 1e2 .. 1e3: rows with
+            # no = 1, optimal False); the next space updates divide by q = dx.C dx near its zero crossing and turn the 1e-8
+            # difference of the two states into 1e-2.  Value parity is therefore asserted while the state is sane (k <= 10:
+            # probe <= 2e-8 measured); after that the run must stay finite, keep the reference's factor count and branch at
+            # every call and cross 64 columns - the functional check of the wide path.
+            assert np.isfinite(r["err"]) and np.isfinite(r["mag"]), r
+            if r["kh"] <= 10:
+                assert r["probe"] < 1e-6, r
+                if r["no"] == r["nh"] and r["no"] > 1:
+                    assert rel < 1e-4, r
+                    tight += 1
+            else:
+                loose += 1
         elif r["sigma"] <= 3.0:
             assert r["no"] == r["nh"] and rel < 1e-5, r
             tight += 1
@@ -478,7 +508,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             loose += 1
     # every call with equal iteration counts carries a value assertion; at least half of all calls must be of that kind
     assert tight + loose >= len(rows) // 2, (tight, loose, len(rows))
-    assert tight >= len(rows) // 3
+    assert tight >= (len(rows) // 3 if not long72 else 40)
 
 
 def test_dct_variance_prior_matches_scipy(dev):
