@@ -175,11 +175,16 @@ __global__ __launch_bounds__(256) void k_gemm_f64(const double* __restrict__ A, 
 // output tile it pulls 85 KB from L2 instead of the 192 KB of the 64 x 32 dense tile (the dense kernel is bound by the
 // ~12 B/clk a CU pulls from L2, not by the f64 matrix cores).  Same MFMA (v_mfma_f64_16x16x4_f64), same LDS row pitch rule.
 // ------------------------------------------------------------------------------------------------
+// per-image diagonal applied to the result of a pass (the m = 0 covariance apply C z = D .* z folded into the forward DCT)
+struct fh_diag_tab {
+  const double* D[FH_MAX_BATCH];  // null table (D[0] == nullptr): no scaling
+};
+
 template <bool INV>
 __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, const double* __restrict__ X,
                                                  double* __restrict__ C, int S, int planes,
                                                  const fh_cg_state* __restrict__ states, const double* __restrict__ add,
-                                                 double add_scale) {
+                                                 double add_scale, fh_diag_tab dg) {
   // K chunks of 64 (two per plane at S = 256): the per-chunk cost besides the 16 MFMA pairs - LDS stores, the barrier, the
   // wait for the prefetched rows - was ~65 % of a 32-wide chunk's time (measured 14.4 us per pass at BK = 32, 36 % of the f64
   // MFMA rate); halving the chunk count halves it.  Two LDS buffers, the next chunk prefetched into registers.
@@ -268,8 +273,10 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
       acc_o = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[kk], bo[kk], acc_o, 0, 0, 0);
     }
     if (kc == nkc - 1) {  // a plane is complete: write its two output row families
-      double* Cp = C + (int64_t)pl[t / nkc] * S * S;
-      const double* Ap = add != nullptr ? add + (int64_t)pl[t / nkc] * S * S : nullptr;
+      const int plane = pl[t / nkc];
+      double* Cp = C + (int64_t)plane * S * S;
+      const double* Ap = add != nullptr ? add + (int64_t)plane * S * S : nullptr;
+      const double* Dp = dg.D[0] != nullptr ? dg.D[plane / 3] + (int64_t)(plane % 3) * S * S : nullptr;
       const int col = r0 + rw + li;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
           o0 = (int64_t)(2 * jj) * S + col, o1 = o0 + S;
           v0 = acc_e[q], v1 = acc_o[q];
         }
+        if (Dp != nullptr) v0 = Dp[o0] * v0, v1 = Dp[o1] * v1;  // same product as k_rep_apply2 forms for m = 0
         Cp[o0] = Ap != nullptr ? fma(add_scale, Ap[o0], v0) : v0;
         Cp[o1] = Ap != nullptr ? fma(add_scale, Ap[o1], v1) : v1;
       }
@@ -303,7 +311,7 @@ static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, in
 // the two symmetric passes: tmp = (X P_w^T)^T, out = P_h X P_w^T (+ add_scale * add); sym_* = packed half bases [2][S/2][S/2]
 static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int planes, const double* sym_w,
                             const double* sym_h, int inverse, const double* add, double add_scale,
-                            const fh_cg_state* states, hipStream_t st) {
+                            const fh_cg_state* states, hipStream_t st, const fh_batch* diag = nullptr) {
   const int S = ctx->S, H = S / 2;
   if (planes > ctx->planes_max || S % 128 != 0) return FH_ESIZE;
   const int gx = S / 32, gy = H / 32;
@@ -322,16 +330,21 @@ static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int 
     attr_set = true;
   }
   const dim3 grid(gx, gy, gz);
+  fh_diag_tab none, dg;
+  memset(&none, 0, sizeof(none));
+  memset(&dg, 0, sizeof(dg));
+  if (diag != nullptr)
+    for (int i = 0; i < diag->nimg && i < FH_MAX_BATCH; ++i) dg.D[i] = diag->D[i];
   if (inverse) {
     hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
-                       (const double*)nullptr, 0.0);
+                       (const double*)nullptr, 0.0, none);
     hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
-                       add, add_scale);
+                       add, add_scale, dg);
   } else {
     hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
-                       (const double*)nullptr, 0.0);
+                       (const double*)nullptr, 0.0, none);
     hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
-                       add, add_scale);
+                       add, add_scale, dg);
   }
   FH_LAUNCH_CHECK();
   return 0;
@@ -1907,6 +1920,13 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per,
     // apply, instead of 4 blur passes + 4 DCT passes + the apply + an axpy epilogue
     if (!p->fold_fwd_h || !p->fold_inv_w || !p->fold_inv_h) return FH_EINVAL;
     if (p->fold_sym) {  // symmetric PSF: the fold pointers are packed half bases (k_dct_sym)
+      if (p->m == 0) {
+        // no factor columns yet (every call above sigma = 10, i.e. three quarters of all CG iterations of a Heun-30 run): C z =
+        // D .* z rides in the epilogue of the forward pass - two kernels per apply instead of three
+        rc = dct2d_launch_sym(ctx, u, w0, planes, p->fold_fwd_w, p->fold_fwd_h, 0, nullptr, 0.0, states, st, &per);
+        if (rc) return rc;
+        return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st);
+      }
       rc = dct2d_launch_sym(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, 0, nullptr, 0.0, states, st);
       if (rc) return rc;
       rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
@@ -1934,7 +1954,15 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per,
     if (rc) return rc;
   }
   // w0 <- C w0  (through the DCT basis when the covariance lives there)
-  if (p->use_dct) {
+  static const bool no_sym_amm = getenv("FH_DCT_NOSYM") != nullptr;
+  if (p->use_dct && p->m == 0 && ctx->sym_fwd != nullptr && !no_sym_amm) {
+    // as above: the diagonal-only covariance apply inside the forward DCT's second pass
+    rc = dct2d_launch_sym(ctx, w0, w1, planes, ctx->sym_fwd, ctx->sym_fwd, 0, nullptr, 0.0, states, st, &per);
+    if (rc) return rc;
+    rc = dct2d_launch_sym(ctx, w1, w0, planes, ctx->sym_inv, ctx->sym_inv, 1, nullptr, 0.0, states, st);
+    if (rc) return rc;
+    { double* t_ = w0; w0 = w1; w1 = t_; }  // the result is expected in w1 below
+  } else if (p->use_dct) {
     rc = dct2d_launch(ctx, w0, w1, planes, 0, states, st);
     if (rc) return rc;
     rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
