@@ -320,7 +320,12 @@ def resizer_apply(x, scale):
 class OracleOperator:
     """The four linear operators.  `noise` is drawn by the caller (RNG is an input, never reproduced)."""
 
-    def __init__(self, name, in_shape, sigma_s, kernel=None, scale_factor=None, mask=None):
+    def __init__(self, name, in_shape, sigma_s, kernel=None, scale_factor=None, mask=None, otf_double=False):
+        """`otf_double` (test-only, NOT the reference's arithmetic): build the blur OTF from the float32 kernel values in
+        complex128 instead of the reference's complex64 (`p2o` of a float32 PSF, utils_sisr.py:22-41).  The operator then
+        equals the exact circular convolution with those taps to 1e-16 instead of 1e-7; used by the tests to separate the
+        OTF rounding from the other differences between the reference and the tap-list kernels."""
+        self.otf_double = bool(otf_double)
         self.name, self.in_shape = name, tuple(in_shape)
         self.sigma_s = torch.tensor([sigma_s], dtype=torch.float32)
         self.scale_factor = scale_factor
@@ -329,7 +334,8 @@ class OracleOperator:
         self.pre_calculated = None
 
     def _k(self):
-        return self.kernel.view(1, 1, *self.kernel.shape)
+        k = self.kernel.view(1, 1, *self.kernel.shape)
+        return k.double() if self.otf_double else k
 
     def forward(self, data, noise=None):
         """y = A x (+ sigma_s * noise); caches pre_calculated like measurements.py:109,146,186."""
@@ -412,10 +418,11 @@ def rtol_func(sigma, rtol_max=1.0, rtol_min=1e-14):
     return 10 ** (f * (math.log10(rtol_max) - math.log10(rtol_min)) + math.log10(rtol_min))
 
 
-def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None):
-    """mat = A^T (A C A^T + sigma_y^2 I)^-1 (y - A x0_mean) by CG; returns same dtype flow as the reference."""
+def system(op, y, x0_mean, cov):
+    """The linear system of the three customcuda solvers (conditioning_mechanisms.py:384-419, 489-527, 641-675):
+    returns (A_mm, b, back, shape) with A_mm(u) = sigma_y^2 u + A C A^T u on flattened measurement-shaped vectors,
+    b = y - A x0_mean and mat = back(solution)."""
     name = op.name
-    rtol = rtol_func(sigma_t, max_rtol)
     C = cov.denoiser_cov_vector_dot
     if name == "inpainting":
         s2 = op.sigma_s.clip(min=0.001) ** 2
@@ -425,12 +432,8 @@ def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None):
             u = u.reshape(x0_mean.shape)
             return (s2 * u + mask * C(mask * u)).flatten()
 
-        b = (mask * y - mask * x0_mean).flatten()
-        sol, info = cg(A_mm, b, rtol=rtol, maxiter=5000)
-        if info["niter"] == 5000:
-            warnings.warn("CG not converge.")
-        mat = sol.reshape(x0_mean.shape)
-    elif name in ("gaussian_blur", "motion_blur"):
+        return A_mm, (mask * y - mask * x0_mean).flatten(), (lambda sol: sol.reshape(x0_mean.shape)), x0_mean.shape
+    if name in ("gaussian_blur", "motion_blur"):
         s2 = op.sigma_s.clip(min=0.001) ** 2
         FB, FBC, _, _ = op.pre_calculated
         blur = lambda v: torch.fft.ifft2(FB * torch.fft.fft2(v)).real
@@ -440,12 +443,8 @@ def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None):
             u = u.reshape(y.shape)
             return (s2 * u + blur(C(blur_t(u)))).flatten()
 
-        b = (y - blur(x0_mean)).flatten()
-        sol, info = cg(A_mm, b, rtol=rtol, maxiter=5000)
-        if info["niter"] == 2000:
-            warnings.warn("CG not converge.")
-        mat = blur_t(sol.reshape(y.shape))
-    elif name == "super_resolution":
+        return A_mm, (y - blur(x0_mean)).flatten(), (lambda sol: blur_t(sol.reshape(y.shape))), y.shape
+    if name == "super_resolution":
         s2 = op.sigma_s.clip(min=0.001).clip(min=1e-2) ** 2
         sf = op.scale_factor
         FB, FBC, _, _ = op.pre_calculated
@@ -456,14 +455,21 @@ def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None):
             u = u.reshape(y.shape)
             return (s2 * u + decimate(blur(C(blur_t(zero_insert(u, sf)))).real, sf)).flatten()
 
-        b = (y - decimate(blur(x0_mean), sf)).real.flatten()
-        sol, info = cg(A_mm, b, rtol=rtol, maxiter=5000)
-        if info["niter"] == 2000:
-            warnings.warn("CG not converge.")
-        mat = blur_t(zero_insert(sol.reshape(y.shape), sf))
-    else:
-        raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
-                         "'motion_blur', or 'inpainting'.")
+        return (A_mm, (y - decimate(blur(x0_mean), sf)).real.flatten(),
+                (lambda sol: blur_t(zero_insert(sol.reshape(y.shape), sf))), y.shape)
+    raise ValueError("Invalid operator name. Please choose 'gaussian_blur', 'super_resolution', "
+                     "'motion_blur', or 'inpainting'.")
+
+
+def solve_mat(op, y, x0_mean, cov, max_rtol, sigma_t, info_out=None, maxiter=5000, rtol=None):
+    """mat = A^T (A C A^T + sigma_y^2 I)^-1 (y - A x0_mean) by CG; returns same dtype flow as the reference.
+    `maxiter` / `rtol` (the reference fixes 5000 and rtol_func) let the tests stop both sides after the same few iterations."""
+    rtol = rtol_func(sigma_t, max_rtol) if rtol is None else rtol
+    A_mm, b, back, _ = system(op, y, x0_mean, cov)
+    sol, info = cg(A_mm, b, rtol=rtol, maxiter=maxiter)
+    if info["niter"] == (5000 if op.name == "inpainting" else 2000):  # the reference's (inconsistent) guards :415, :521, :669
+        warnings.warn("CG not converge.")
+    mat = back(sol)
     if info_out is not None:
         info_out.append({"niter": info["niter"], "optimal": info["optimal"],
                          "residual_norm": float(info["residual_norm"]), "rtol": rtol})
@@ -553,7 +559,7 @@ class OracleFreeHunch:
         if analytic:
             g = g * self.cond_scaling
             rec["branch"] = "vjp"
-        elif (g * sig2).std() > self.err_thr:  # :283-285
+        elif rec.setdefault("std", float((g * sig2).std())) > self.err_thr:  # :283-285
             g = self.cov.denoiser_cov_vector_dot(mat.detach()) * self.cond_scaling / sig2
             rec["branch"] = "cov"
         else:

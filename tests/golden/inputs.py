@@ -31,6 +31,26 @@ SMALL_C = UNetConfig(image_size=256, num_channels=32, num_res_blocks=1, channel_
                      use_scale_shift_norm=True, resblock_updown=True, use_new_attention_order=False)
 
 
+# ---- denoisers for which the reference reproduces itself across hosts (tests/golden/make_golden.py: *_tight, tmpd_*_pos)
+GAUSS_PRIOR_VAR = 0.25
+DAMP = 0.05
+
+
+def gauss_prior_denoise(x, sigma, var=GAUSS_PRIOR_VAR):
+    """Posterior mean of a N(0, var I) prior at noise level sigma: linear in x, contractive, no clamp."""
+    return x * (var / (var + sigma ** 2))
+
+
+def damped_state(seeded_state, cfg, seed, damp=DAMP):
+    """`seeded_state` weights with the last convolution (out.2) scaled by `damp`: F = UNet(c_in x) stays small, so the
+    denoiser D = clamp(x - sigma F) has a Jacobian close to the clamp mask and the sampler does not amplify the 1e-5
+    differences between two fp32 UNet implementations (a random-weight UNet at full scale does)."""
+    sd = seeded_state(cfg, seed)
+    for k in ("out.2.weight", "out.2.bias"):
+        sd[k] = sd[k] * damp
+    return sd
+
+
 def script(seed, shape, n_steps, sig0, neg_gamma_at=None, sig_end=0.5):
     """A scripted alternation of time and space updates with seeded vectors (mimics the Heun call pattern)."""
     g = rng(seed)

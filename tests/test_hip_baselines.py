@@ -196,3 +196,51 @@ def test_online_covariance_customscipy_vs_reference_golden(dev, gold, tag, tmp_p
         assert all(abs(a - b) <= 0.25 * b + 1 for a, b in zip(n_hip, n_ref)), (n_hip, n_ref)
         return
     assert err < 1e-3, err  # tol 1e-4 solves on the well-conditioned SR system: north-star tolerance on the final image
+
+
+@pytest.mark.parametrize("tag", ["tmpd_gb_gauss", "tmpd_ip_damped", "tmpd_sr_damped"])
+def test_tmpd_positive_variance_field_vs_reference_golden(dev, gold, tag, tmp_path):
+    """TMPD (conditioning_mechanisms.py:112-133 with the scipy solvers :360-381, :463-484, :616-639) on EVERY call: the
+    recordings of baselines_tmpd_pos.npz use denoisers whose Jacobian row sums are non-negative - the closed-form
+    Gaussian-prior denoiser (a constant positive field) and the UNet with a damped output layer (clamp mask x (1 - small)) -
+    so sigma_y^2 I + A diag(theta) A^T is positive definite and the solve is a property of the system (with the random-weight
+    UNet of baselines_perpixel.npz it is indefinite from the second call on, see above).  The reference solves in float32
+    scipy CG at tol = rtol_func_2(sigma) (1e-4 .. 1); here the float64 device CG in scipy's iteration semantics.  Asserted:
+    every call's estimate checksum and the final image (north-star 1e-3)."""
+    import nets
+    from free_hunch_amd.sampler import conditional_sampler
+    from test_hip_parity import _base_kwargs, _hip_op
+    g = gold("baselines_tmpd_pos")
+    c = baseline_inputs(g, tag)
+    kind = str(g[c["p"] + "net"])
+    net = nets.gauss_net(64, dev) if kind == "gauss" else nets.damped_hip_net(inputs.SMALL_A, int(g["unet_seed"]), dev)
+    mask = torch.from_numpy(g[c["p"] + "mask"]).float().repeat(1, 3, 1, 1) if c["opname"] == "inpainting" else None
+    op = _hip_op(c["opname"], 64, dev, mask)
+    kw = _base_kwargs(tmp_path, {"conditioning_mechanism": c["mech"], "diffpir_lambda": 10.0, "pigdm_posthoc_scaling": False,
+                                 **c["over"]})
+    sums = []
+    import free_hunch_amd.conditioning_mechanisms as cm
+    cls = cm.choose_conditioning_mechanism(c["mech"])
+    orig = cls.x0_mean_update
+
+    def recording(self, x_t, model, y, sigma):
+        out = orig(self, x_t, model, y, sigma)
+        sums.append(float(out.detach().double().sum()))
+        return out
+
+    cls.x0_mean_update = recording
+    try:
+        x, _all, _y = conditional_sampler(net, c["noise"].to(dev), None, None, num_steps=c["nsteps"], sigma_min=0.002,
+                                          sigma_max=80, rho=7, solver=c["solver"], measurement=c["y"].to(dev), operator=op,
+                                          **kw)
+    finally:
+        cls.x0_mean_update = orig
+    ref = torch.from_numpy(g[c["p"] + "x_final"])
+    ref_sums = np.asarray(g[c["p"] + "out_sum"])
+    assert len(sums) == len(ref_sums)
+    dev_sums = np.abs(np.array(sums) - ref_sums) / (np.abs(ref_sums) + (3 * 64 * 64) ** 0.5)
+    err = float((x.detach().cpu() - ref).abs().max())
+    _perpixel_report(tag, {"calls": len(sums), "max_checksum_dev": float(dev_sums.max()), "final_max_abs": err,
+                           "checksum_dev": [float(v) for v in dev_sums]})
+    assert float(dev_sums.max()) < 5e-4, dev_sums
+    assert err < 1e-3, err

@@ -400,9 +400,12 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     y, sigma) and keeps its own covariance state.  Per call: identical factor count and vjp/cov branch; for
     sigma <= 3 (the steps that determine the final image) identical CG iteration counts and outputs within 1e-5 of
     max|out| (measured: 1e-6 .. 1e-10); above that, within 1e-4 whenever both solves are short (<= 20 iterations,
-    sigma < 20), i.e. outside the rounding-chaotic regime described above."""
+    sigma < 20), i.e. outside the rounding-chaotic regime described above.  The long un-converged solves (their iterate
+    moves by 1e-2 under a 1e-16 perturbation in the reference's own arithmetic, tests/test_cg_sensitivity.py) are held to
+    what IS reproducible: the iterates after 6 iterations agree to 1e-6 of max|mat| (iteration map at that state), and the
+    HIP solution's true residual in the ORACLE's system meets the reference's stopping rule (5 % slack)."""
     from oracle import fh_oracle as fo
-    from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate
+    from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate, solve_customcuda
     from test_oracle_golden import _mk_op
     g = gold("trajectories")
     analytic = tag.endswith("+analytic")  # use_analytic_var_at_end = true (scalar-variance closed form below sigma 0.2)
@@ -460,6 +463,16 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             if long72:
                 co = self.o.cov.denoiser_cov_vector_dot(probe)
                 rows[-1]["probe"] = maxabs(co, self.h.covariance_model.denoiser_cov_vector_dot(probe.to(dev))) / float(co.abs().max())
+            elif th["rtol"] > 2e-2 and to["niter"] > 20 and not th.get("analytic"):
+                s_, r = float(sigma), rows[-1]
+                u_h = solve_customcuda.last_solution.clone()
+                m6h = solve_customcuda(hop, y_.to(dev), self.h.denoiser_means[-1], self.h.covariance_model, 1.0, s_, rtol=0.0,
+                                       maxiter=6)
+                m6o = fo.solve_mat(self.o.op, y_, self.o.means[-1], self.o.cov, 1.0, s_, maxiter=6, rtol=0.0)
+                r["short"] = maxabs(m6o, m6h) / float(m6o.abs().max())
+                A_mm, b, _back, _shape = fo.system(self.o.op, y_, self.o.means[-1], self.o.cov)
+                r["res_true_hip"] = float((b - A_mm(T(u_h).double().flatten())).norm()) / float(b.norm())
+                r["res_rec_oracle"] = float(to["residual_norm"]) / float(b.norm())
             return out_o
 
     fo.conditional_sampler(onet, noise, y, oop, num_steps=72 if long72 else int(g[p + "num_steps"]), solver=str(g[p + "solver"]),
@@ -499,12 +512,10 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
         elif r["no"] == r["nh"] and r["no"] <= 20 and r["sigma"] < 20:
             assert rel < 1e-4, r
             tight += 1
-        elif r["no"] == r["nh"]:
-            # an un-converged iterate of a long solve at high sigma (rtol 0.1 .. 1): equal iteration counts, but the oracle
-            # blurs through the reference's complex64 OTF (6e-8 per frequency) and cond(A C A^T + s^2 I) ~ 1e6 amplifies
-            # that difference in an iterate that is still far from the solution (measured: up to 0.28 of max|out| at
-            # sigma > 30 with k = 0, 1e-2 typically) - a sanity bound, the values are in the report
-            assert rel < 0.5, r
+        elif "short" in r:
+            # an un-converged iterate of a long solve at high sigma (rtol 0.04 .. 1): see the docstring
+            assert r["short"] < 1e-6, r
+            assert r["res_true_hip"] <= 1.05 * max(r["rtol"], r["res_rec_oracle"]) + 1e-9, r
             loose += 1
     # every call with equal iteration counts carries a value assertion; at least half of all calls must be of that kind
     assert tight + loose >= len(rows) // 2, (tight, loose, len(rows))

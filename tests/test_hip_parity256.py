@@ -18,6 +18,7 @@ import pytest
 import torch
 
 import inputs
+import nets
 from test_hip_parity import T, _base_kwargs, _hip_op, maxabs
 
 pytestmark = pytest.mark.gpu
@@ -450,25 +451,59 @@ def test_free_running_headline_configs_64(dev, gold, tag, tmp_path):
     assert abs(rec_dev["niter_sum_hip"] - rec_dev["niter_sum_ref"]) <= 0.25 * rec_dev["niter_sum_ref"], rec_dev
 
 
-@pytest.mark.parametrize("tag", ["gb256_heun30", "mb256_heun30", "sr256_heun30", "ip256_heun30"])
-def test_free_running_trajectory_256_vs_reference_golden(dev, gold, tag):
-    """one 256 x 256 Heun-30 trajectory per operator, shipped DCT prior, 32-channel UNet with the
+FREE_256 = [("trajectories256", "gb256_heun30", 16), ("trajectories256", "mb256_heun30", 16),
+            ("trajectories256", "sr256_heun30", 16), ("trajectories256", "ip256_heun30", 16),
+            ("trajectories256_euler", "ip256_euler100", 28)]
+
+
+@pytest.mark.parametrize("fixture,tag,k_last", FREE_256)
+def test_free_running_trajectory_256_vs_reference_golden(dev, gold, fixture, tag, k_last):
+    """one 256 x 256 Heun-30 trajectory per operator, and BASELINE configs[3] (inpainting, Euler,
+    num_steps = 100: 100 guidance calls, 28 BFGS pairs -> m = 56 factor columns) - shipped DCT prior, 32-channel UNet with the
     ImageNet-256 block structure (attention at T = 1024 / 256 / 64), recorded from the reference's conditional_sampler, run
-    free with the HIP UNet.  59 guidance calls through a random-weight UNet amplify the 1e-5 differences between two fp32
-    UNet implementations, so beyond the first calls the trajectories decorrelate for every operator (the report lists the
-    first call whose estimate differs).  Asserted: exact k (16 pairs at the end) and sigma sequences; the first guidance
-    call reproduces the recording (identical CG iteration count, estimate checksum to 1e-6); total CG work within 5 % and
-    branch decisions within a quarter of the calls; and the same reconstruction statistics as the reference against the
-    ground truth (PSNR within 2.5 dB; these are saturated random-UNet outputs at 6 - 8 dB)."""
-    g = gold("trajectories256")
+    free with the HIP UNet.  The guidance solves of these configurations stop un-converged on cond ~ 1e6 systems
+    (tests/test_cg_sensitivity.py: the reference's own iterate moves by 1e-2 under a 1e-16 perturbation) and a random-weight
+    UNet amplifies the 1e-5 differences between two fp32 UNet implementations, so the trajectories decorrelate from the
+    first call on for every operator (the report lists the first call whose estimate differs: call 0).  Asserted: exact k
+    (16 / 28 pairs at the end) and sigma sequences; the first solve's iteration count within 15 % (measured 0 - 12 %); total
+    CG work within 5 % and branch decisions within a quarter of the calls; and the same reconstruction statistics as the
+    reference against the ground truth (PSNR within 2.5 dB; these are saturated random-UNet outputs at 6 - 8 dB).  Value
+    parity of the same path lives in the call-by-call tests (test_teacher_forced_256, test_state_following_euler100_256)
+    and, end to end within 1e-3, in test_free_running_converged_256_within_1e3 below."""
+    g = gold(fixture)
     rec, tr = _free_run(g, tag, 256, _small_net(inputs.SMALL_C, int(g["unet_seed"]), dev), dev, DATA, 4, "hip-unet")
-    assert rec["k_equal"] and tr[-1]["k"] == 16
-    # even the first solve (sigma = 80, rtol = 1, up to 258 iterations on a cond ~ 1e6 system) stops a few iterations apart:
-    # its count must agree to 15 % (measured: 0 - 12 %), the total to 5 %
+    assert rec["k_equal"] and tr[-1]["k"] == k_last
     assert abs(rec["niter_hip"][0] - rec["niter_ref"][0]) <= 0.15 * rec["niter_ref"][0] + 1, rec
     assert rec["branch_mismatch_calls"] <= rec["calls"] // 4, rec
     assert abs(rec["niter_sum_hip"] - rec["niter_sum_ref"]) <= 0.05 * rec["niter_sum_ref"], rec
     assert abs(rec["psnr_hip_vs_truth_db"] - rec["psnr_ref_vs_truth_db"]) < 2.5, rec  # measured 0.0 - 1.5 dB
+
+
+TIGHT_256 = ["gb256_heun12_tight_gauss", "ip256_heun12_tight_damped", "sr256_euler16_tight_damped", "mb256_heun8_tight_gauss"]
+
+
+@pytest.mark.parametrize("tag", TIGHT_256)
+def test_free_running_converged_256_within_1e3(dev, gold, tag):
+    """North star: "outputs match the reference PyTorch CPU path on identical seeds within 1e-3 max-abs" - END TO END, free
+    running, at full size, against recordings of the reference's `conditional_sampler`, in the configurations where the
+    reference reproduces ITSELF across hosts (measured with the oracle under a 1e-16 / 1e-6 perturbation: 5e-7 / 1.5e-4 in
+    the final image, against 0.9 - 1.3 with the default max_rtol = 1):
+      * max_rtol = 1e-6 (a CLI flag of the reference, config.yaml): every guidance solve converges, so its result is a
+        property of the system and no longer of the rounding history;
+      * a denoiser that does not amplify: the closed-form Gaussian-prior denoiser (`*_gauss`: exercises the whole Free Hunch
+        path, all calls on the vjp branch) or the HIP UNet with a damped output layer (`*_damped`: UNet forward + input-VJP
+        through the clamp, both branches).
+    Asserted: identical k and branch lists, per-call CG iteration counts within 2 % + 2 (converged counts move by a few
+    iterations with the summation order), and the final image within 1e-3 max-abs of the reference's."""
+    g = gold("trajectories256_tight")
+    p = tag + "__"
+    net = nets.gauss_net(256, dev) if str(g[p + "net"]) == "gauss" else nets.damped_hip_net(inputs.SMALL_C, int(g["unet_seed"]), dev)
+    rec, tr = _free_run(g, tag, 256, net, dev, DATA, 2, "hip-" + str(g[p + "net"]))
+    assert rec["k_equal"], rec
+    assert rec["branch_mismatch_calls"] == 0, rec
+    assert all(abs(a - b) <= 0.02 * b + 2 for a, b in zip(rec["niter_hip"], rec["niter_ref"])), rec
+    assert rec["final_max_abs"] < 1e-3, rec
+    assert abs(float(g[p + "x_final_absmax"]) - rec["ref_abs_max"]) < 1.0  # (the strided sample is representative)
 
 
 def test_free_running_sr256_with_reference_unet_arithmetic(dev, gold):
@@ -499,11 +534,18 @@ def test_teacher_forced_256(dev, gold, opname, tag):
         (measured <= 1.5e-7 after 8 space + 11 time updates; below sigma = 0.2 the reference's own arithmetic is 3e-7 ..
         1.4e-6 off the exact update, this build 1e-8: test_forward_time_shift_accuracy_vs_extended_precision);
       * value parity: converged solves (rtol <= 1e-4: the steps that fix the final image) within 1e-5 of max|out|;
-      * system parity for the un-converged solves: at sigma >= 1 the reference stops CG at rtol 0.04 .. 1 on a system of
-        condition ~ 1e6, where the iterate moves by kappa x the 1e-10 state difference (measured: mat differs by 4e-4 after
-        12 equal iterations, the guidance C mat by 4 %; a 2-iteration difference moves it by 60 %).  There the iterate is
-        not a property of the system, so the first two such calls re-solve both sides at rtol 1e-6 and compare THOSE
-        (measured <= 5e-7 of max|mat|; bound 1e-5); the loose outputs get a sanity bound and go to the report."""
+      * the un-converged solves (sigma >= 1: the reference stops CG at rtol 0.04 .. 1 on a system of condition ~ 1e6).  Their
+        iterate is NOT a property of the system: tests/test_cg_sensitivity.py shows on the reference's own arithmetic that a
+        1e-16 perturbation of the right-hand side moves the 40th iterate by 1e-3 .. 1e-1 (and that the complex64 OTF is just
+        one such perturbation).  Asserted for every such call instead:
+          - the iteration map: both sides stopped after 6 iterations agree to 1e-6 of max|mat| (operators, covariance apply and
+            CG recurrences at that state; the reference's complex64 OTF bounds it at ~1e-8), and to 1e-9 + 50 x the state
+            difference against the oracle with a complex128 OTF (inpainting: no OTF);
+          - equal validity: the HIP solution's TRUE residual in the ORACLE's system, ||b - (s^2 I + A C A^T)_oracle u_hip||,
+            meets the reference's stopping rule rtol ||b|| as well as the oracle's own iterate does (5 % slack);
+          - for the first two such calls both sides are re-solved at rtol 1e-6 and THOSE agree to 1e-5 (measured <= 5e-7);
+        the deviation of the un-converged outputs themselves goes to the report next to the oracle's own deviation under the
+        1e-16 perturbation (`self_dev`, first three such calls) - same order of magnitude, no assertion."""
     from oracle import fh_oracle as fo, unet_oracle as uo
     from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate, solve_customcuda
     from test_oracle_golden import _mk_op
@@ -535,6 +577,32 @@ def test_teacher_forced_256(dev, gold, opname, tag):
                               rtol=rt)
         return maxabs(mo, mh) / float(mo.abs().max()), io[0]["niter"], ih[0]["niter"]
 
+    oop128 = None
+    if opname != "inpainting":  # the same operator with a complex128 OTF (test-only option of the oracle)
+        oop128 = _mk_op(opname, size, g, p)
+        oop128.otf_double = True
+        oop128.forward(inputs.smooth_image(size, s_img))
+    ulp = 1 + 1e-16 * inputs.randn(tuple(y.shape), 5)
+
+    def unconverged(pair, y_, sigma, r):
+        """the three checks of an un-converged call (docstring); fills r"""
+        s_, cov_o, x0_o = float(sigma), pair.o.cov, pair.o.means[-1]
+        x0_h, cov_h = pair.h.denoiser_means[-1], pair.h.covariance_model
+        u_h = solve_customcuda.last_solution.clone()  # the solution of THIS call's solve
+        m6h = solve_customcuda(hop, y_.to(dev), x0_h, cov_h, 1.0, s_, rtol=0.0, maxiter=6)
+        m6o = fo.solve_mat(pair.o.op, y_, x0_o, cov_o, 1.0, s_, maxiter=6, rtol=0.0)
+        r["short"] = maxabs(m6o, m6h) / float(m6o.abs().max())
+        m6x = m6o if oop128 is None else fo.solve_mat(oop128, y_, x0_o, cov_o, 1.0, s_, maxiter=6, rtol=0.0)
+        r["short_exact_op"] = maxabs(m6x, m6h) / float(m6x.abs().max())
+        A_mm, b, _back, _shape = fo.system(pair.o.op, y_, x0_o, cov_o)
+        nb = float(b.norm())
+        r["res_true_hip"] = float((b - A_mm(T(u_h).double().flatten())).norm()) / nb
+        r["res_rec_oracle"] = float(pair.o.trace[-1]["residual_norm"]) / nb
+        if sum("self_dev" in q for q in rows) < 3:
+            mo = fo.solve_mat(pair.o.op, y_, x0_o, cov_o, 1.0, s_)
+            mp = fo.solve_mat(pair.o.op, y_.double() * ulp, x0_o, cov_o, 1.0, s_)
+            r["self_dev"] = maxabs(mo, mp) / float(mo.abs().max())
+
     class Pair:
         def __init__(self, op_, v0, d):
             self.o = fo.OracleFreeHunch(1.0, op_, False, v0, d, image_base_covariance="dct_diagonal", data_dir=DATA)
@@ -556,8 +624,10 @@ def test_teacher_forced_256(dev, gold, opname, tag):
                      ko=to["k"], kh=th["k"], err=maxabs(out_o, out_h), mag=float(out_o.abs().max()), rtol=float(th["rtol"]),
                      cov_probe=maxabs(co, self.h.covariance_model.denoiser_cov_vector_dot(probe.to(dev)))
                      / float(co.abs().max()))
-            if r["rtol"] > 1e-4 and r["err"] > 1e-5 * r["mag"] and sum("tight" in q for q in rows) < 2:
-                r["tight"], r["tight_no"], r["tight_nh"] = resolve_tight(self, y_, sigma)
+            if r["rtol"] > 2e-2:  # an un-converged solve (sigma >= 1)
+                unconverged(self, y_, sigma, r)
+                if sum("tight" in q for q in rows) < 2:
+                    r["tight"], r["tight_no"], r["tight_nh"] = resolve_tight(self, y_, sigma)
             rows.append(r)
             if len(rows) >= ncalls:
                 raise Stop()
@@ -579,14 +649,98 @@ def test_teacher_forced_256(dev, gold, opname, tag):
         assert r["cov_probe"] < 1e-6, r  # measured <= 1.5e-7; the reference's own float64 arithmetic is 3e-7 .. 1.4e-6 off there
         if "tight" in r:
             assert r["tight"] < 1e-5 and abs(r["tight_no"] - r["tight_nh"]) <= 0.05 * r["tight_no"] + 2, r
+        if "short" in r:  # un-converged: iteration map + equal validity (docstring)
+            assert r["short"] < 1e-6, r
+            assert r["short_exact_op"] < 1e-9 + 50 * r["cov_probe"], r
+            assert r["res_true_hip"] <= 1.05 * max(r["rtol"], r["res_rec_oracle"]) + 1e-9, r
         if r["no"] == r["nh"]:
             equal += 1
-            assert r["err"] / r["mag"] < (1e-5 if r["rtol"] <= 1e-4 else 0.5), r
+            if r["rtol"] <= 2e-2:  # sigma <= 0.43: measured <= 2e-6 (rtol 0.011) and <= 3e-7 (rtol <= 4e-4)
+                assert r["err"] / r["mag"] < (1e-5 if r["rtol"] <= 1e-3 else 1e-4), r
         else:
             assert abs(r["no"] - r["nh"]) <= 0.1 * r["no"] + 2, r
     assert sum(r["rtol"] <= 1e-4 and r["no"] == r["nh"] for r in rows) >= 4  # the converged tail carries value assertions
     assert equal >= (2 * ncalls) // 3
     assert rows[-1]["kh"] >= 4
+
+
+def test_state_following_euler100_256(dev, gold, monkeypatch):
+    """BASELINE configs[3] on real states: inpainting, Euler, num_steps = 100 at 256 x 256 (100 guidance calls, 28 BFGS pairs
+    -> m = 56 factor columns), inputs of the reference's recording (trajectories256_euler.npz).  The HIP sampler runs free
+    (HIP UNet, default flags) and the ORACLE's covariance object follows it: every `update_time_step` / `update_space_step`
+    the HIP plugin issues is replayed on the oracle with the same tensors.  (Driving the whole trajectory from the oracle, as
+    test_teacher_forced_256 does, costs 6 min of CPU for 100 calls; the states this run visits are just as real.)
+    Asserted at every update: the predicted mean / score of the time update and the covariance apply on a probe agree to 1e-6
+    relative up to m = 56 (the reference's own float64 arithmetic is 3e-7 .. 1.4e-6 off the exact update below sigma = 0.2,
+    test_forward_time_shift_accuracy_vs_extended_precision); identical factor counts; k reaches 28.  For guidance calls at
+    k = 28 whose solve converges (rtol <= 1e-3, every sixth one): the HIP solve against the oracle's `solve_mat` on the same
+    state and inputs to 1e-5 of max|mat| with the same iteration count +- 1."""
+    from oracle import fh_oracle as fo
+    from free_hunch_amd import covariance as hc, conditioning_mechanisms as cm
+    from free_hunch_amd.sampler import conditional_sampler, get_sigma_steps
+    from test_oracle_golden import _mk_op
+    g = gold("trajectories256_euler")
+    tag, size = "ip256_euler100", 256
+    p = tag + "__"
+    d = 3 * size * size
+    mask = T(g[p + "mask"]).float().repeat(1, 3, 1, 1)
+    hop, oop = _hip_op("inpainting", size, dev, mask), _mk_op("inpainting", size, g, p)
+    noise = inputs.randn((1, 3, size, size), int(g[p + "seeds"][1]), torch.float32).to(dev)
+    y = T(g[p + "y"])
+    net = _small_net(inputs.SMALL_C, int(g["unet_seed"]), dev)
+    sigma0 = float(net.round_sigma(get_sigma_steps("edm", 100, 0.002, min(80.0, net.sigma_max), 7, dev))[0])
+    ocov = fo.make_covariance("dct_diagonal", DATA, sigma0 ** 2, d)
+    probe = inputs.randn((1, 3, size, size), 99, torch.float64)
+    rows, solves = [], []
+    orig_t, orig_s = hc.CovarianceHessianBFGSDCT.update_time_step, hc.CovarianceHessianBFGSDCT.update_space_step
+
+    def rel(a, b):
+        return maxabs(a, b) / max(1e-300, float(T(b).abs().max()))
+
+    def probe_err(self):
+        co = ocov.denoiser_cov_vector_dot(probe)
+        return rel(self.denoiser_cov_vector_dot(probe.to(dev)), co)
+
+    def time_step(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance=False):
+        out = orig_t(self, x_t, sigma_t, sigma_tnext, score_t, only_covariance)
+        mo, so = ocov.update_time_step(T(x_t).double(), float(sigma_t), float(sigma_tnext), T(score_t).double(), only_covariance)
+        rows.append(dict(what="time", k=self.k, ko=ocov.k, sigma=float(sigma_tnext), mean=rel(out[0], mo), score=rel(out[1], so),
+                         probe=probe_err(self) if self.k % 4 == 0 else 0.0))
+        return out
+
+    def space_step(self, m0, m1, sigma_t, x, xn):
+        orig_s(self, m0, m1, sigma_t, x, xn)
+        ocov.update_space_step(T(m0).double(), T(m1).double(), float(sigma_t), T(x).double(), T(xn).double())
+        rows.append(dict(what="space", k=self.k, ko=ocov.k, sigma=float(sigma_t), mean=0.0, score=0.0, probe=probe_err(self)))
+
+    monkeypatch.setattr(hc.CovarianceHessianBFGSDCT, "update_time_step", time_step)
+    monkeypatch.setattr(hc.CovarianceHessianBFGSDCT, "update_space_step", space_step)
+    orig_solve = cm.solve_customcuda
+
+    def solve(operator, y_, x0_mean, cov, max_rtol, sigma_t, info_out=None, **kw_):
+        mat = orig_solve(operator, y_, x0_mean, cov, max_rtol, sigma_t, info_out, **kw_)
+        if cov.k == 28 and info_out and info_out[-1]["rtol"] <= 1e-3 and len(rows) % 6 == 0:
+            io = []
+            mo = fo.solve_mat(oop, y, T(x0_mean).double(), ocov, max_rtol, float(sigma_t), io)
+            solves.append(dict(sigma=float(sigma_t), nh=info_out[-1]["niter"], no=io[0]["niter"], err=rel(mat, mo)))
+        return mat
+
+    monkeypatch.setattr(cm, "solve_customcuda", solve)
+    conditional_sampler(net, noise, None, None, num_steps=100, sigma_min=0.002, sigma_max=80, rho=7, solver="euler",
+                        measurement=y.to(dev), operator=hop, **_base_kwargs(DATA, {}))
+    tr = conditional_sampler.last_mechanism.trace
+    _report(f"{tag}[state-following]", {"updates": len(rows), "solves": solves,
+                                        "max_mean": max(r["mean"] for r in rows), "max_score": max(r["score"] for r in rows),
+                                        "max_probe": max(r["probe"] for r in rows),
+                                        "probe_by_k": {str(r["k"]): r["probe"] for r in rows if r["what"] == "space"}})
+    assert len(tr) == 100 and [t["k"] for t in tr] == list(g[p + "k"]) and tr[-1]["k"] == 28
+    assert conditional_sampler.last_mechanism.covariance_model.famC.m == 56
+    for r in rows:
+        assert r["k"] == r["ko"], r
+        assert r["mean"] < 1e-6 and r["score"] < 1e-6 and r["probe"] < 1e-6, r
+    assert len(solves) >= 3, solves
+    for q in solves:
+        assert q["err"] < 1e-5 and abs(q["nh"] - q["no"]) <= 1, q
 
 
 def test_groups_equal_single_group(dev):
