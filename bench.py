@@ -67,6 +67,10 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
     enc = StandardRGBEncoder()
     S = images_u8.shape[-1]
+    prof = os.environ.get("FH_PHASE_TIMES")
+    if prof:
+        torch.cuda.synchronize()
+    t_setup = time.perf_counter()
     ops, ys, noises = [], [], []
     for b, (img, seed) in enumerate(zip(images_u8, seeds)):
         np.random.seed(int(seed) % (1 << 31))
@@ -81,6 +85,9 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
         noises.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(int(seed) % (1 << 31)),
                                   dtype=torch.float32))
     B = len(ops)
+    if prof:
+        torch.cuda.synchronize()
+        print(f"[FH_PHASE_TIMES] run_batch setup (operators, measurements, noise): {time.perf_counter() - t_setup:.3f} s", flush=True)
     groups = max(1, min(groups, B))
     bounds = [round(g * B / groups) for g in range(groups + 1)]
     main = torch.cuda.current_stream()

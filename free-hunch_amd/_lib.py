@@ -65,6 +65,10 @@ _SIGS = {
     "fh_cov_time_update": ([C.c_void_p, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_int,
                             c_dp, c_dp, c_dp, c_dp, C.c_void_p], C.c_int),
     "fh_cov_space_update": ([C.c_void_p, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, c_dp, c_dp, C.c_void_p], C.c_int),
+    "fh_cov_time_update_batched": ([C.c_void_p, C.c_int, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, C.c_double, C.c_double,
+                                    c_dp, c_dp, c_dp, C.c_void_p], C.c_int),
+    "fh_cov_space_update_batched": ([C.c_void_p, C.c_int, C.POINTER(FhCovState), c_dp, c_dp, C.c_double, c_dp, c_dp, c_dp,
+                                     C.c_void_p], C.c_int),
     "fh_woodbury_inner": ([C.c_void_p, c_dp, C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_axpby": ([C.c_double, c_dp, C.c_double, c_dp, c_dp, C.c_int64, C.c_void_p], C.c_int),
     "fh_read_scalars": ([C.c_void_p, c_dp, C.POINTER(C.c_double), C.c_int, C.c_void_p], C.c_int),

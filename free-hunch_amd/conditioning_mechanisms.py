@@ -350,6 +350,37 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             score_previous = (self.denoiser_means[-1] - self.xs[-1]) / self.sigmas[-1] ** 2
             cm.update_time_step(self.xs[-1], self.sigmas[-1], s, score_previous, only_covariance=True)
 
+    @staticmethod
+    def fh_update_batched(mechs, x_all, m_all, sigma, prev_x_all, prev_m_all, changed, slot=0):
+        """`fh_update` of the B plugin instances of a lock-step batch with ONE kernel sequence per covariance update
+        (CovarianceHessianBFGS.update_*_step_batched) instead of one per image.  x_all, m_all: this call's x_t and denoiser
+        output [B,3,S,S]; prev_x_all, prev_m_all: the previous call's (None on the first call); `changed`: per image
+        `not torch.allclose(x, x_prev)` (:250).  Returns False - nothing done - when the batch does not qualify (different
+        column counts, factor tracking, a network-score time update, images that did not move): the caller then falls
+        back to per-image `fh_update`."""
+        a = mechs[0]
+        covs = [mm.covariance_model for mm in mechs]
+        s = float(sigma)
+        if not (a.do_space_updates and a.use_analytical_score_time_update and CovarianceHessianBFGS.can_batch(covs)):
+            return False
+        if any(mm.sigmas != a.sigmas or mm.do_space_updates != a.do_space_updates
+               or mm.space_step_update_threshold != a.space_step_update_threshold
+               or mm.space_step_update_lower_threshold != a.space_step_update_lower_threshold for mm in mechs):
+            return False
+        if len(a.sigmas) == 0:
+            return True  # first call: no update
+        if prev_x_all is None or prev_m_all is None or changed is None or not all(changed):
+            return False
+        pred = prev_m_all
+        if s != a.sigmas[-1]:
+            score_prev = (prev_m_all - prev_x_all) / a.sigmas[-1] ** 2
+            pred, _ = CovarianceHessianBFGS.update_time_step_batched(covs, prev_x_all, a.sigmas[-1], s, score_prev, slot=slot)
+        if a.space_step_update_lower_threshold < s < a.space_step_update_threshold:
+            if not CovarianceHessianBFGS.can_batch(covs):  # (column count after the time update is unchanged; re-check capacity)
+                return False
+            CovarianceHessianBFGS.update_space_step_batched(covs, pred, m_all, s, prev_x_all, x_all, slot=slot)
+        return True
+
     def fh_branch(self, p_y_xt_grad, sigma, std=None):
         """"cov" when the VJP guidance is judged unreliable (std(vjp * sigma^2) > threshold, :283), else "vjp" """
         if self._rec.get("analytic"):  # :277-278: always the VJP form

@@ -354,6 +354,80 @@ class CovarianceHessianBFGS:
         new_mean = self.ctx.axpby(1.0, x, sigma_tnext ** 2, new_score, torch.empty_like(x))
         return self._bwd(new_mean).reshape(shape), self._bwd(new_score).reshape(shape)
 
+    # ------------------------------------------------------------------ lock-step batches (one launch sequence for B images)
+    @staticmethod
+    def can_batch(models):
+        """True when `update_*_step_batched` applies: one-call update path for every image (<= 62 columns, no factor
+        tracking, no truncation), same basis / column counts / capacities - what a lock-step batch normally satisfies."""
+        a = models[0]
+        if os.environ.get("FH_COV_STEPWISE") == "1" or os.environ.get("FH_COV_BATCH", "1") == "0" or len(models) < 2:
+            return False
+        if max(a.famC.m, a.famH.m) + 2 > 64:
+            return False
+        if a.max_vector_count is not None and a.max_vector_count < 32:  # a truncation could trigger (k <= 31 on this path)
+            return False
+        return all((not mm._track) and mm.use_dct == a.use_dct and mm.famC.m == a.famC.m and mm.famH.m == a.famH.m
+                   and mm.data_dim == a.data_dim and mm.m_cap == a.m_cap and mm.C.M_dev.shape[1] == a.C.M_dev.shape[1]
+                   and bool(mm.project_to_diagonal) == bool(a.project_to_diagonal) and mm.device == a.device
+                   and mm.max_vector_count == a.max_vector_count for mm in models)
+
+    @staticmethod
+    def _batch_ctx(models, slot):
+        a = models[0]
+        return _lib.Context.get(a.S, 3 * len(models), 64, slot=9000 + 64 * slot + len(models))
+
+    @staticmethod
+    def _batch_states(models):
+        arr = (_lib.FhCovState * len(models))()
+        for i, mm in enumerate(models):
+            C.memmove(C.byref(arr[i]), C.byref(mm._state()), C.sizeof(_lib.FhCovState))
+        return arr
+
+    @staticmethod
+    def update_time_step_batched(models, x_all, sigma_t, sigma_tnext, score_all, slot=0):
+        """`update_time_step` of B covariance objects in ONE kernel sequence (fh_cov_time_update_batched; the kernels of the
+        per-object call with the image as a grid dimension: bitwise the same result per image).  x_all, score_all:
+        [B,3,S,S] float64 contiguous.  Returns (mean' [B,3,S,S], score' [B,3,S,S])."""
+        a = models[0]
+        B, d = len(models), a.data_dim
+        sigma_t, sigma_tnext = float(sigma_t), float(sigma_tnext)
+        shift_c = float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2)))  # float32-rounded like the reference (:166, :172)
+        shift_h = -float(np.float32(sigma_tnext ** 2 - sigma_t ** 2))
+        ctx = CovarianceHessianBFGS._batch_ctx(models, slot)
+        x = x_all.detach().to(device=a.device, dtype=F64).contiguous()
+        sc = score_all.detach().to(device=a.device, dtype=F64).contiguous()
+        work = torch.empty(3, B, d, dtype=F64, device=a.device)
+        mean, score = torch.empty_like(x), torch.empty_like(x)
+        sts = CovarianceHessianBFGS._batch_states(models)
+        _lib.check(ctx.lib.fh_cov_time_update_batched(ctx.h, B, sts, _lib.ptr(x), _lib.ptr(sc), shift_c, shift_h,
+                                                      sigma_tnext ** 2, _lib.ptr(work), _lib.ptr(mean), _lib.ptr(score),
+                                                      _lib.stream()), "fh_cov_time_update_batched")
+        for mm in models:
+            mm.C.m, mm.H.m = mm.famC.m, mm.famH.m
+        return mean, score
+
+    @staticmethod
+    def update_space_step_batched(models, mean_x_all, mean_xn_all, sigma_t, x_all, xn_all, slot=0):
+        """`update_space_step` of B covariance objects in ONE kernel sequence (fh_cov_space_update_batched)."""
+        a = models[0]
+        B, d = len(models), a.data_dim
+        s2 = float(sigma_t) ** 2
+        project = bool(a.project_to_diagonal)
+        mc, mh = a.famC.m, a.famH.m
+        for mm in models:
+            mm._ensure_capacity(max(mc if project else mc + 2, mh + 2))
+        ctx = CovarianceHessianBFGS._batch_ctx(models, slot)
+        vecs = [t.detach().to(device=a.device, dtype=F64).contiguous() for t in (mean_x_all, mean_xn_all, x_all, xn_all)]
+        work = torch.empty(3, B, d, dtype=F64, device=a.device)
+        sts = CovarianceHessianBFGS._batch_states(models)
+        _lib.check(ctx.lib.fh_cov_space_update_batched(ctx.h, B, sts, _lib.ptr(vecs[0]), _lib.ptr(vecs[1]), s2, _lib.ptr(vecs[2]),
+                                                       _lib.ptr(vecs[3]), _lib.ptr(work), _lib.stream()),
+                   "fh_cov_space_update_batched")
+        for mm in models:
+            if not project:
+                mm.famC.m = mm.C.m = mm.Ci.m = mc + 2
+            mm.famH.m = mm.H.m = mm.Hi.m = mh + 2
+
     # ------------------------------------------------------------------ :250-312
     def update_space_step(self, denoiser_mean_at_x, denoiser_mean_at_xnext, sigma_t, x, xnext):
         assert x.shape[0] == 1, "Batch size must be 1"

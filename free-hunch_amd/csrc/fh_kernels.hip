@@ -26,6 +26,19 @@ struct RtolArr {
   double v[FH_MAX_BATCH];
 };
 
+// Per-image pointer table of a lock-step batch (passed by value in the kernel arguments; the image is a grid dimension).
+// The covariance-update kernels below take their per-image operands this way, so that ONE launch sequence updates all
+// images of a batch; the single-image entry points pass a table with one entry (same kernels, same arithmetic).
+struct PtrTab {
+  double* p[FH_MAX_BATCH];
+};
+static inline PtrTab tab1(const double* q) {
+  PtrTab t;
+  memset(&t, 0, sizeof(t));
+  t.p[0] = const_cast<double*>(q);
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // float64 GEMM for the two DCT passes on the matrix cores (v_mfma_f64_16x16x4_f64):
 //   C = A * op(B),  A [M][K] (lda), C [M][N] (ldc),  BT ? B [N][K] : B [K][N]  (ldb).
@@ -887,9 +900,12 @@ static int rep_apply_launch(fh_context* ctx, const fh_batch& per, int ldm, const
 //                   (one LDS read per operand per 1024 FMAs; sub-tiles beyond column m are skipped)
 //   k_gram_reduce : sums the row-block partials, writes both triangles
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, const double* __restrict__ rx,
-                                                     double shift, double* __restrict__ Dy, double* __restrict__ ry,
+__global__ __launch_bounds__(256) void k_invert_diag(PtrTab Dxt, PtrTab rxt, double shift, PtrTab Dyt, PtrTab ryt,
                                                      int64_t d) {
+  double* __restrict__ Dx = Dxt.p[blockIdx.z];
+  const double* __restrict__ rx = rxt.p[blockIdx.z];
+  double* __restrict__ Dy = Dyt.p[blockIdx.z];
+  double* __restrict__ ry = ryt.p[blockIdx.z];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= d) return;
   const double v = Dx[i] + shift;
@@ -899,8 +915,10 @@ __global__ __launch_bounds__(256) void k_invert_diag(double* __restrict__ Dx, co
 }
 
 // forward time shift of a representation and of its inverse: D <- D / (1 + s D), r <- r / (1 + s D), Dinv <- Dinv + s
-__global__ __launch_bounds__(256) void k_forward_diag(double* __restrict__ D, double* __restrict__ r,
-                                                      double* __restrict__ Dinv, double s, int64_t d) {
+__global__ __launch_bounds__(256) void k_forward_diag(PtrTab Dt, PtrTab rt_, PtrTab Dinvt, double s, int64_t d) {
+  double* __restrict__ D = Dt.p[blockIdx.z];
+  double* __restrict__ r = rt_.p[blockIdx.z];
+  double* __restrict__ Dinv = Dinvt.p[blockIdx.z];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= d) return;
   const double e = 1.0 / fma(s, D[i], 1.0);
@@ -914,9 +932,12 @@ constexpr int kGT = 64;  // Gram tile edge and row-chunk length
 
 // fwd = 0: weights rx^2 / Dx (Woodbury inverse of the representation); fwd = 1: rx^2 / (1 + fshift Dx) (forward time
 // shift of the representation itself, see cov_shift_forward)
-__global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, const double* __restrict__ rx,
-                                              const double* __restrict__ Dx, double* __restrict__ gpartial,
-                                              int64_t d, int m, int ntiles, int fwd, double fshift) {
+__global__ __launch_bounds__(256) void k_gram(PtrTab Bt, PtrTab rxt, PtrTab Dxt, double* __restrict__ gpartial,
+                                              int64_t gstride, int64_t d, int m, int ntiles, int fwd, double fshift) {
+  const double* __restrict__ B = Bt.p[blockIdx.z];   // grid z = image
+  const double* __restrict__ rx = rxt.p[blockIdx.z];
+  const double* __restrict__ Dx = Dxt.p[blockIdx.z];
+  gpartial += (int64_t)blockIdx.z * gstride;
   __shared__ double As[kGT][kGT + 1];  // [row i][col of tile a], weighted
   __shared__ double Bs[kGT][kGT + 1];  // [row i][col of tile b]
   // decode tile pair
@@ -988,8 +1009,10 @@ __global__ __launch_bounds__(256) void k_gram(const double* __restrict__ B, cons
     for (int r = 0; r < 4; ++r) dst[(16 * wave + lk + 4 * r) * kGT + 16 * j + li] = acc[j][r];
   }
 }
-__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ gpartial, int nrb, int ntiles, int m,
-                                                     double* __restrict__ G, int ldg) {
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ gpartial, int64_t gstride, int nrb,
+                                                     int ntiles, int m, PtrTab Gt, int ldg) {
+  double* __restrict__ G = Gt.p[blockIdx.z];
+  gpartial += (int64_t)blockIdx.z * gstride;
   // grid (tile pairs, 64): a workgroup owns 64 consecutive tile outputs; its 4 waves each sum a quarter of the nrb
   // row-block partials (coalesced 512-byte rows, 4 independent chains), then the quarters are added in a fixed order.
   int ta = 0, tb = 0, p = blockIdx.x;
@@ -1088,18 +1111,24 @@ __global__ __launch_bounds__(256) void k_dot_partial(const double* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void k_scalar_reduce(const double* __restrict__ part, int nparts,
-                                                       double* __restrict__ dst) {
+// grid x = image: dst[img][slot] = sum of that image's partials
+__global__ __launch_bounds__(256) void k_scalar_reduce(const double* __restrict__ part, int64_t part_stride, int nparts,
+                                                       PtrTab dst, int slot) {
   __shared__ double red[4];
+  part += (int64_t)blockIdx.x * part_stride;
   double s = threadIdx.x < nparts ? part[threadIdx.x] : 0.0;
   s = block_sum_256(s, red);
-  if (threadIdx.x == 0) *dst = s;
+  if (threadIdx.x == 0) dst.p[blockIdx.x][slot] = s;
 }
 
 __global__ __launch_bounds__(256) void k_space_prep(const double* __restrict__ dm, double s2,
                                                     const double* __restrict__ dx, double* __restrict__ de,
-                                                    double* __restrict__ part, int64_t n) {
+                                                    double* __restrict__ part, int64_t part_stride, int64_t n) {
   __shared__ double red[4];
+  dm += (int64_t)blockIdx.z * n;  // grid z = image: the vectors of a batch are contiguous [image][n]
+  dx += (int64_t)blockIdx.z * n;
+  de += (int64_t)blockIdx.z * n;
+  part += (int64_t)blockIdx.z * part_stride;
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const double e = s2 * dm[i];
@@ -1114,14 +1143,25 @@ __global__ __launch_bounds__(256) void k_space_prep(const double* __restrict__ d
 // pair to the inner matrices: Mc gets diag(gamma, -1/q) at (mc, mc+1) unless projected, Mh diag(gamma, -1/q) / s2^2 at
 // (mh, mh+1); the new rows / columns are cleared first.  No scalar returns to the host.
 __global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__ de, const double* __restrict__ cdx,
-                                                      double gamma, double q, double s2, double* __restrict__ Dc,
-                                                      const double* __restrict__ rc, double* __restrict__ bc0,
-                                                      double* __restrict__ bc1, double* __restrict__ Dh,
-                                                      const double* __restrict__ rh, double* __restrict__ bh0,
-                                                      double* __restrict__ bh1, int project, int64_t n,
-                                                      const double* __restrict__ scal, double* __restrict__ Mc, int ldc,
-                                                      int mc, double* __restrict__ Mh, int ldh, int mh) {
-  if (scal != nullptr) {
+                                                      double gamma, double q, double s2, PtrTab Dct, PtrTab rct, PtrTab bc0t,
+                                                      PtrTab bc1t, PtrTab Dht, PtrTab rht, PtrTab bh0t, PtrTab bh1t,
+                                                      int project, int64_t n, int use_scal, PtrTab scalt, PtrTab Mct, int ldc,
+                                                      int mc, PtrTab Mht, int ldh, int mh) {
+  const int img = blockIdx.z;  // grid z = image; de, cdx contiguous [image][n]
+  de += (int64_t)img * n;
+  cdx += (int64_t)img * n;
+  double* __restrict__ Dc = Dct.p[img];
+  const double* __restrict__ rc = rct.p[img];
+  double* __restrict__ bc0 = bc0t.p[img];
+  double* __restrict__ bc1 = bc1t.p[img];
+  double* __restrict__ Dh = Dht.p[img];
+  const double* __restrict__ rh = rht.p[img];
+  double* __restrict__ bh0 = bh0t.p[img];
+  double* __restrict__ bh1 = bh1t.p[img];
+  if (use_scal) {
+    const double* __restrict__ scal = scalt.p[img];
+    double* __restrict__ Mc = Mct.p[img];
+    double* __restrict__ Mh = Mht.p[img];
     gamma = 1.0 / scal[0];
     q = scal[1];
     if (blockIdx.x == 0) {
@@ -1168,16 +1208,21 @@ __global__ __launch_bounds__(256) void k_space_commit(const double* __restrict__
 constexpr int kWbMaxCols = 64;  // = kWbMax below: the device-side m x m algebra handles up to 64 columns
 
 // part[b] = sum over block b of a^2 .* w   (de^T D^-1 de of the closed-form BFGS inverse)
-__global__ __launch_bounds__(256) void k_wnorm_partial(const double* __restrict__ a, const double* __restrict__ w,
-                                                       double* __restrict__ part, int64_t n) {
+__global__ __launch_bounds__(256) void k_wnorm_partial(const double* __restrict__ a, PtrTab wt,
+                                                       double* __restrict__ part, int64_t part_stride, int64_t n) {
   __shared__ double red[4];
+  const double* __restrict__ w = wt.p[blockIdx.z];  // grid z = image; a contiguous [image][n]
+  a += (int64_t)blockIdx.z * n;
+  part += (int64_t)blockIdx.z * part_stride;
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(a[i] * a[i], w[i], s);
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void k_copy_small(const double* __restrict__ src, double* __restrict__ dst, int n) {
+__global__ __launch_bounds__(256) void k_copy_small(const double* __restrict__ src, int64_t src_stride, PtrTab dstt, int n) {
+  src += (int64_t)blockIdx.x * src_stride;  // grid x = image
+  double* __restrict__ dst = dstt.p[blockIdx.x];
   for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
@@ -1189,9 +1234,13 @@ __global__ __launch_bounds__(256) void k_copy_small(const double* __restrict__ s
 // The generic Woodbury route passes through the singular matrix C - v v^T (v = C dx / sqrt(dx^T C dx)) and loses
 // cond(I + G M) ~ 1e9 of the 1e16 at d = 196608 with the DCT prior; this form has no cancellation.
 // scal: [0] dx.de, [2] de^T D^-1 de;  cC = M t (mc);  sCi = s, cCi = Mi s (mc).  One workgroup.
-__global__ __launch_bounds__(256) void k_bfgs_inverse_commit(const double* __restrict__ scal, const double* __restrict__ cC,
-                                                             const double* __restrict__ sCi, const double* __restrict__ cCi,
-                                                             double* __restrict__ Mi, int ld, int mc) {
+__global__ __launch_bounds__(256) void k_bfgs_inverse_commit(PtrTab scalt, PtrTab cCt, const double* __restrict__ coef,
+                                                             int64_t coef_stride, PtrTab Mit, int ld, int mc) {
+  const double* __restrict__ scal = scalt.p[blockIdx.x];  // grid x = image
+  const double* __restrict__ cC = cCt.p[blockIdx.x];
+  const double* __restrict__ cCi = coef + (int64_t)blockIdx.x * coef_stride;  // c = Mi s of the dots pass ...
+  const double* __restrict__ sCi = cCi + FH_MAX_COLS;                         // ... and s = Wi^T de itself
+  double* __restrict__ Mi = Mit.p[blockIdx.x];
   __shared__ double a[kWbMaxCols + 2], b[kWbMaxCols + 2];
   __shared__ double rho_s;
   const int tid = threadIdx.x, n = mc + 2;
@@ -1555,9 +1604,13 @@ __device__ __forceinline__ void dd_fma(dd_acc& s, double a, double b) {
 }
 
 // scratch: 4 m^2 doubles of global memory (A as hi / lo pairs, the residual, the last correction), private to this launch
-__global__ __launch_bounds__(256) void k_woodbury_inner(const double* __restrict__ Msrc, int lds_, const double* __restrict__ G,
-                                                        int ldg, double* __restrict__ Mdst, int ldd, int m, double alpha,
-                                                        double sign, double* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void k_woodbury_inner(PtrTab Msrct, int lds_, PtrTab Gt, int ldg, PtrTab Mdstt, int ldd, int m,
+                                                        double alpha, double sign, double* __restrict__ scratch,
+                                                        int64_t scratch_stride) {
+  const double* __restrict__ Msrc = Msrct.p[blockIdx.x];  // grid x = image (one workgroup each)
+  const double* __restrict__ G = Gt.p[blockIdx.x];
+  double* __restrict__ Mdst = Mdstt.p[blockIdx.x];
+  scratch += (int64_t)blockIdx.x * scratch_stride;
   extern __shared__ __align__(16) double wb[];
   const int w = 2 * m + 1;          // row pitch of the augmented matrix (odd: conflict-free column walks)
   const int q = m + 1;
@@ -2180,7 +2233,11 @@ int fh_context_create(fh_context** out, int S, int planes_max, int m_cap) {
   }
   const int ntiles = (m_cap + kGT - 1) / kGT;
   const int npairs = ntiles * (ntiles + 1) / 2;
-  c->gpartial_elems = (int64_t)(npairs > 0 ? npairs : 1) * kGramRowBlocks * kGT * kGT;
+  // Gram partials: one image at the context's column capacity, or (batched covariance updates, <= 64 columns: one tile
+  // pair) every image of a batch side by side
+  const int pairs_batched = m_cap > 0 ? c->nimg_max : 0;
+  const int pairs = npairs > pairs_batched ? npairs : pairs_batched;
+  c->gpartial_elems = (int64_t)(pairs > 0 ? pairs : 1) * kGramRowBlocks * kGT * kGT;
   FH_CHECK(hipMalloc(&c->basis, sizeof(double) * S * S));
   FH_CHECK(hipMalloc(&c->basis_t, sizeof(double) * S * S));
   FH_CHECK(hipMemcpy(c->basis, bas.data(), sizeof(double) * S * S, hipMemcpyHostToDevice));
@@ -2302,24 +2359,45 @@ int fh_rep_apply_batched(fh_context* ctx, const fh_batch* per, int ldm, const do
   return rep_apply_launch(ctx, *per, ldm, z, out, d, m, nullptr, (hipStream_t)stream);
 }
 
+// ---- batched internals: every per-image operand arrives as a PtrTab, vectors of a batch are contiguous [image][d] ----
+static inline int gram_pairs(int m) {
+  const int ntiles = (m + kGT - 1) / kGT;
+  return ntiles * (ntiles + 1) / 2;
+}
+
+static int rep_invert_b(fh_context* ctx, int nimg, PtrTab Dx, PtrTab rx, PtrTab B, double shift, PtrTab Dy, PtrTab ry,
+                        PtrTab G, int ldg, int64_t d, int m, hipStream_t st) {
+  const unsigned Z = (unsigned)nimg;
+  // Gram uses the shifted diagonal: apply the shift first, then read Dx
+  hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256), 1, Z), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
+  if (m > 0) {
+    const int ntiles = (m + kGT - 1) / kGT;
+    const int npairs = gram_pairs(m);
+    const int64_t gstride = (int64_t)npairs * kGramRowBlocks * kGT * kGT;
+    if (gstride * nimg > ctx->gpartial_elems) return FH_ESIZE;
+    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs, Z), dim3(256), 0, st, B, rx, Dx, ctx->gpartial, gstride, d, m, ntiles, 0,
+                       0.0);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64, Z), dim3(256), 0, st, (const double*)ctx->gpartial, gstride,
+                       kGramRowBlocks, ntiles, m, G, ldg);
+  }
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
 int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B, double shift, double* Dy,
                   double* ry, double* G, int ldg, int64_t d, int m, void* stream) {
   if (!ctx || !Dx || !Dy || d < 1 || m < 0 || m > ctx->m_cap) return FH_EINVAL;
   if (m > 0 && (!rx || !ry || !B || !G || ldg < m)) return FH_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  if (m > 0) {
-    // Gram uses the shifted diagonal: apply the shift first, then read Dx
-    hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
-    const int ntiles = (m + kGT - 1) / kGT;
-    const int npairs = ntiles * (ntiles + 1) / 2;
-    if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems) return FH_ESIZE;
-    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, st, B, rx, (const double*)Dx,
-                       ctx->gpartial, d, m, ntiles, 0, 0.0);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64), dim3(256), 0, st, (const double*)ctx->gpartial, kGramRowBlocks,
-                       ntiles, m, G, ldg);
-  } else {
-    hipLaunchKernelGGL(k_invert_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, Dx, rx, shift, Dy, ry, d);
-  }
+  return rep_invert_b(ctx, 1, tab1(Dx), tab1(rx), tab1(B), shift, tab1(Dy), tab1(ry), tab1(G), ldg, d, m, (hipStream_t)stream);
+}
+
+// de <- s2 dm; scal[img][0] = dx.de
+static int space_prep_b(fh_context* ctx, int nimg, const double* dm, double s2, const double* dx, double* de, PtrTab scal,
+                        int64_t d, hipStream_t st) {
+  hipLaunchKernelGGL(k_space_prep, dim3(kDotBlocks, 1, (unsigned)nimg), dim3(256), 0, st, dm, s2, dx, de, ctx->w2,
+                     (int64_t)kCgScratch, d);
+  hipLaunchKernelGGL(k_scalar_reduce, dim3((unsigned)nimg), dim3(256), 0, st, (const double*)ctx->w2, (int64_t)kCgScratch,
+                     kDotBlocks, scal, 0);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -2327,21 +2405,22 @@ int fh_rep_invert(fh_context* ctx, double* Dx, const double* rx, const double* B
 int fh_space_prep(fh_context* ctx, const double* dm, double s2, const double* dx, double* de, double* scal,
                   int64_t d, void* stream) {
   if (!ctx || !dm || !dx || !de || !scal) return FH_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_space_prep, dim3(kDotBlocks), dim3(256), 0, st, dm, s2, dx, de, ctx->w2, d);
-  hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, st, (const double*)ctx->w2, kDotBlocks, scal);
+  return space_prep_b(ctx, 1, dm, s2, dx, de, tab1(scal), d, (hipStream_t)stream);
+}
+
+// scal[img][slot] = a[img] . b[img]
+static int dot_b(fh_context* ctx, int nimg, const double* a, const double* b, PtrTab scal, int slot, int64_t d, hipStream_t st) {
+  hipLaunchKernelGGL(k_dot_partial, dim3(kDotBlocks, 1, (unsigned)nimg), dim3(256), 0, st, a, b, (const double*)nullptr,
+                     (const double*)nullptr, ctx->w2, d, kCgScratch, (const fh_cg_state*)nullptr);
+  hipLaunchKernelGGL(k_scalar_reduce, dim3((unsigned)nimg), dim3(256), 0, st, (const double*)ctx->w2, (int64_t)kCgScratch,
+                     kDotBlocks, scal, slot);
   FH_LAUNCH_CHECK();
   return 0;
 }
 
 int fh_dot(fh_context* ctx, const double* a, const double* b, double* scal, int slot, int64_t d, void* stream) {
   if (!ctx || !a || !b || !scal || slot < 0) return FH_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_dot_partial, dim3(kDotBlocks), dim3(256), 0, st, a, b, (const double*)nullptr,
-                     (const double*)nullptr, ctx->w2, d, 0, (const fh_cg_state*)nullptr);
-  hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, st, (const double*)ctx->w2, kDotBlocks, scal + slot);
-  FH_LAUNCH_CHECK();
-  return 0;
+  return dot_b(ctx, 1, a, b, tab1(scal), slot, d, (hipStream_t)stream);
 }
 
 int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double gamma, double q, double s2,
@@ -2349,9 +2428,10 @@ int fh_space_commit(fh_context* ctx, const double* de, const double* cdx, double
                     double* Bh_col0, double* Bh_col1, int project, int64_t d, void* stream) {
   if (!ctx || !de || !cdx || !Dc || !Dh || !Bh_col0 || !Bh_col1) return FH_EINVAL;
   if (!project && (!Bc_col0 || !Bc_col1)) return FH_EINVAL;
-  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, gamma, q, s2, Dc, rc,
-                     Bc_col0, Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d, (const double*)nullptr, (double*)nullptr, 0, 0,
-                     (double*)nullptr, 0, 0);
+  const PtrTab none = tab1(nullptr);
+  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, gamma, q, s2, tab1(Dc), tab1(rc),
+                     tab1(Bc_col0), tab1(Bc_col1), tab1(Dh), tab1(rh), tab1(Bh_col0), tab1(Bh_col1), project, d, 0, none, none, 0,
+                     0, none, 0, 0);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -2362,23 +2442,15 @@ int fh_space_commit_dev(fh_context* ctx, const double* de, const double* cdx, co
                         int project, int64_t d, void* stream) {
   if (!ctx || !de || !cdx || !scal || !Dc || !Dh || !Bh_col0 || !Bh_col1 || !Mh || mh < 0 || ldh < mh + 2) return FH_EINVAL;
   if (!project && (!Bc_col0 || !Bc_col1 || !Mc || mc < 0 || ldc < mc + 2)) return FH_EINVAL;
-  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, 0.0, 0.0, s2, Dc, rc, Bc_col0,
-                     Bc_col1, Dh, rh, Bh_col0, Bh_col1, project, d, scal, Mc, ldc, mc, Mh, ldh, mh);
+  hipLaunchKernelGGL(k_space_commit, dim3(512), dim3(256), 0, (hipStream_t)stream, de, cdx, 0.0, 0.0, s2, tab1(Dc), tab1(rc),
+                     tab1(Bc_col0), tab1(Bc_col1), tab1(Dh), tab1(rh), tab1(Bh_col0), tab1(Bh_col1), project, d, 1, tab1(scal),
+                     tab1(Mc), ldc, mc, tab1(Mh), ldh, mh);
   FH_LAUNCH_CHECK();
   return 0;
 }
 
-static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
-                        int m, double alpha, double sign, void* stream);
-
-int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
-                      int m, void* stream) {
-  return inner_update(ctx, Msrc, ld_src, G, ldg, Mdst, ld_dst, m, 1.0, -1.0, stream);
-}
-
-static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
-                        int m, double alpha, double sign, void* stream) {
-  if (!ctx || m < 0 || (m > 0 && (!Msrc || !G || !Mdst || ld_src < m || ldg < m || ld_dst < m))) return FH_EINVAL;
+static int inner_update_b(fh_context* ctx, int nimg, PtrTab Msrc, int ld_src, PtrTab G, int ldg, PtrTab Mdst, int ld_dst, int m,
+                          double alpha, double sign, hipStream_t st) {
   if (m == 0) return 0;
   if (m > kWbMax) return FH_ESIZE;  // the caller falls back to its host path
   const size_t lds = ((size_t)m * (2 * m + 1) + 2 * (size_t)m * (m + 1) + (m <= kWbLdsMax ? 3 * (size_t)m * m : 0)) * sizeof(double);
@@ -2388,12 +2460,19 @@ static int inner_update(fh_context* ctx, const double* Msrc, int ld_src, const d
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     attr_set = true;
   }
-  if (ctx->gpartial_elems < (int64_t)4 * m * m) return FH_ESIZE;
+  const int64_t sstride = (int64_t)4 * kWbMax * kWbMax;
+  if (ctx->gpartial_elems < sstride * nimg) return FH_ESIZE;
   // ctx->gpartial: the Gram partials were reduced into G before this launch (stream order); free until the next k_gram
-  hipLaunchKernelGGL(k_woodbury_inner, dim3(1), dim3(256), lds, (hipStream_t)stream, Msrc, ld_src, G, ldg, Mdst, ld_dst, m,
-                     alpha, sign, ctx->gpartial);
+  hipLaunchKernelGGL(k_woodbury_inner, dim3((unsigned)nimg), dim3(256), lds, st, Msrc, ld_src, G, ldg, Mdst, ld_dst, m, alpha, sign,
+                     ctx->gpartial, sstride);
   FH_LAUNCH_CHECK();
   return 0;
+}
+
+int fh_woodbury_inner(fh_context* ctx, const double* Msrc, int ld_src, const double* G, int ldg, double* Mdst, int ld_dst,
+                      int m, void* stream) {
+  if (!ctx || m < 0 || (m > 0 && (!Msrc || !G || !Mdst || ld_src < m || ldg < m || ld_dst < m))) return FH_EINVAL;
+  return inner_update_b(ctx, 1, tab1(Msrc), ld_src, tab1(G), ldg, tab1(Mdst), ld_dst, m, 1.0, -1.0, (hipStream_t)stream);
 }
 
 int fh_axpby(double alpha, const double* a, double beta, const double* b, double* out, int64_t n, void* stream) {
@@ -2403,12 +2482,34 @@ int fh_axpby(double alpha, const double* a, double beta, const double* b, double
   return 0;
 }
 
-// ---- whole covariance updates (see fh_hip.h): the step-by-step entry points, enqueued from C in covariance.py's order
-static int cov_invert(fh_context* ctx, const fh_cov_state* st, int src, int dst, const double* B, int m, double shift,
-                      void* stream) {
-  int rc = fh_rep_invert(ctx, st->D[src], st->r[src], B, shift, st->D[dst], st->r[dst], st->G, st->ldg, st->d, m, stream);
+// ---- whole covariance updates (see fh_hip.h): the step-by-step entry points, enqueued from C in covariance.py's order, for
+// ONE image (fh_cov_time_update / fh_cov_space_update) or for all images of a lock-step batch in one launch sequence
+// (fh_cov_*_update_batched: same kernels with grid z = image, so an image's result does not depend on the batch it is in).
+struct CovB {
+  int nimg;
+  const fh_cov_state* st[FH_MAX_BATCH];
+};
+enum CovField { F_D, F_R, F_M, F_BC, F_BH, F_G, F_SCAL };
+static PtrTab cov_tab(const CovB& cb, CovField f, int rep = 0, int64_t offset = 0) {
+  PtrTab t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < cb.nimg; ++i) {
+    const fh_cov_state* s = cb.st[i];
+    double* q = f == F_D ? s->D[rep] : f == F_R ? s->r[rep] : f == F_M ? s->M[rep] : f == F_BC ? s->Bc : f == F_BH ? s->Bh
+                : f == F_G ? s->G : s->scal;
+    t.p[i] = q ? q + offset : nullptr;
+  }
+  return t;
+}
+
+static int cov_invert_b(fh_context* ctx, const CovB& cb, int src, int dst, CovField base, int m, double shift, hipStream_t sq) {
+  const fh_cov_state* s0 = cb.st[0];
+  if (m > 0 && s0->ldg < m) return FH_ESIZE;
+  int rc = rep_invert_b(ctx, cb.nimg, cov_tab(cb, F_D, src), cov_tab(cb, F_R, src), cov_tab(cb, base), shift, cov_tab(cb, F_D, dst),
+                        cov_tab(cb, F_R, dst), cov_tab(cb, F_G), s0->ldg, s0->d, m, sq);
   if (rc) return rc;
-  return fh_woodbury_inner(ctx, st->M[src], st->ldm, st->G, st->ldg, st->M[dst], st->ldm, m, stream);
+  return inner_update_b(ctx, cb.nimg, cov_tab(cb, F_M, src), s0->ldm, cov_tab(cb, F_G), s0->ldg, cov_tab(cb, F_M, dst), s0->ldm, m,
+                        1.0, -1.0, sq);
 }
 
 // Forward time shift  X <- (X^-1 + s I)^-1  computed from X's OWN representation (online_update_bfgs.py:166-167, 172-173):
@@ -2417,102 +2518,173 @@ static int cov_invert(fh_context* ctx, const fh_cov_state* st, int src, int dst,
 // Equal to inverting the shifted inverse representation (what the reference does), but I + s G M has the eigenvalues of
 // I + s X restricted to the factor span - in [1, (sigma / sigma')^2] for the covariance, [1, 2) for the Hessian - whereas
 // the inverse route weights the Gram by 1 / D (1e-4 .. 1e4 with the DCT prior) and loses up to 1e9 of the 1e16.
-static int cov_shift_forward(fh_context* ctx, const fh_cov_state* st, int fwd, int inv, const double* B, int m, double s,
-                             void* stream) {
-  hipStream_t sq = (hipStream_t)stream;
-  const int64_t d = st->d;
+static int cov_shift_forward_b(fh_context* ctx, const CovB& cb, int fwd, int inv, CovField base, int m, double s, hipStream_t sq) {
+  const fh_cov_state* s0 = cb.st[0];
+  const int64_t d = s0->d;
+  const unsigned Z = (unsigned)cb.nimg;
   if (m > 0) {
     const int ntiles = (m + kGT - 1) / kGT;
-    const int npairs = ntiles * (ntiles + 1) / 2;
-    if ((int64_t)npairs * kGramRowBlocks * kGT * kGT > ctx->gpartial_elems || st->ldg < m) return FH_ESIZE;
-    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs), dim3(256), 0, sq, B, (const double*)st->r[fwd],
-                       (const double*)st->D[fwd], ctx->gpartial, d, m, ntiles, 1, s);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64), dim3(256), 0, sq, (const double*)ctx->gpartial,
-                       kGramRowBlocks, ntiles, m, st->G, st->ldg);
+    const int npairs = gram_pairs(m);
+    const int64_t gstride = (int64_t)npairs * kGramRowBlocks * kGT * kGT;
+    if (gstride * cb.nimg > ctx->gpartial_elems || s0->ldg < m) return FH_ESIZE;
+    hipLaunchKernelGGL(k_gram, dim3(kGramRowBlocks, npairs, Z), dim3(256), 0, sq, cov_tab(cb, base), cov_tab(cb, F_R, fwd),
+                       cov_tab(cb, F_D, fwd), ctx->gpartial, gstride, d, m, ntiles, 1, s);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs, kGT * kGT / 64, Z), dim3(256), 0, sq, (const double*)ctx->gpartial, gstride,
+                       kGramRowBlocks, ntiles, m, cov_tab(cb, F_G), s0->ldg);
   }
-  hipLaunchKernelGGL(k_forward_diag, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, sq, st->D[fwd], st->r[fwd], st->D[inv],
-                     s, d);
+  hipLaunchKernelGGL(k_forward_diag, dim3((unsigned)((d + 255) / 256), 1, Z), dim3(256), 0, sq, cov_tab(cb, F_D, fwd),
+                     cov_tab(cb, F_R, fwd), cov_tab(cb, F_D, inv), s, d);
   FH_LAUNCH_CHECK();
   if (m == 0) return 0;
-  return inner_update(ctx, st->M[fwd], st->ldm, st->G, st->ldg, st->M[fwd], st->ldm, m, s, 1.0, stream);
+  return inner_update_b(ctx, cb.nimg, cov_tab(cb, F_M, fwd), s0->ldm, cov_tab(cb, F_G), s0->ldg, cov_tab(cb, F_M, fwd), s0->ldm, m, s,
+                        1.0, sq);
 }
 
-static int cov_fwd(fh_context* ctx, const fh_cov_state* st, const double* in, double* out, int inverse, void* stream) {
-  if (st->use_dct) return fh_dct2d(ctx, in, out, 3, inverse, stream);
-  if (in != out) return fh_axpby(1.0, in, 0.0, nullptr, out, st->d, stream);
+static int cov_fwd_b(fh_context* ctx, const CovB& cb, const double* in, double* out, int inverse, hipStream_t sq) {
+  if (cb.st[0]->use_dct) return dct2d_launch(ctx, in, out, 3 * cb.nimg, inverse, nullptr, sq);
+  if (in != out) return fh_axpby(1.0, in, 0.0, nullptr, out, cb.st[0]->d * cb.nimg, sq);
   return 0;
+}
+
+static fh_batch rep_batch(const CovB& cb, int rep, CovField base) {
+  fh_batch per;
+  memset(&per, 0, sizeof(per));
+  per.nimg = cb.nimg;
+  for (int i = 0; i < cb.nimg; ++i) {
+    const fh_cov_state* s = cb.st[i];
+    per.D[i] = s->D[rep], per.r[i] = s->r[rep], per.B[i] = base == F_BC ? s->Bc : s->Bh, per.M[i] = s->M[rep];
+  }
+  return per;
+}
+
+// the images of a batch must agree on everything that shapes the launch
+static int cov_batch_check(fh_context* ctx, const CovB& cb) {
+  if (cb.nimg < 1 || cb.nimg > FH_MAX_BATCH || cb.nimg > ctx->nimg_max || 3 * cb.nimg > ctx->planes_max) return FH_ESIZE;
+  const fh_cov_state* a = cb.st[0];
+  for (int i = 0; i < cb.nimg; ++i) {
+    const fh_cov_state* s = cb.st[i];
+    if (!s || s->d != a->d || s->m_c != a->m_c || s->m_h != a->m_h || s->ldm != a->ldm || s->ldg != a->ldg ||
+        s->project != a->project || s->use_dct != a->use_dct)
+      return FH_EINVAL;
+  }
+  return 0;
+}
+
+// x, score, wx, ws, t0, mean_out, score_out: [nimg][d] contiguous
+static int time_update_b(fh_context* ctx, const CovB& cb, const double* x, const double* score, double shift_c, double shift_h,
+                         double sigma_next2, int only_covariance, double* wx, double* ws, double* t0, double* mean_out,
+                         double* score_out, hipStream_t sq) {
+  const fh_cov_state* s0 = cb.st[0];
+  if (s0->m_c > kWbMax || s0->m_h > kWbMax) return FH_ESIZE;
+  const int64_t d = s0->d, dn = d * cb.nimg;
+  int rc = cov_shift_forward_b(ctx, cb, 0, 1, F_BC, s0->m_c, shift_c, sq);  // C <- (C^-1 + shift)^-1, C^-1 += shift
+  if (rc || only_covariance) return rc;
+  if (!x || !score || !wx || !ws || !t0 || !mean_out || !score_out) return FH_EINVAL;
+  if ((rc = cov_fwd_b(ctx, cb, x, wx, 0, sq))) return rc;
+  if ((rc = cov_fwd_b(ctx, cb, score, ws, 0, sq))) return rc;
+  // t0 = H^-1 score with the OLD Hessian, then H <- (H^-1 + shift)^-1, new score = H t0
+  if ((rc = rep_apply_launch(ctx, rep_batch(cb, 3, F_BH), s0->ldm, ws, t0, d, s0->m_h, nullptr, sq))) return rc;
+  if ((rc = cov_shift_forward_b(ctx, cb, 2, 3, F_BH, s0->m_h, shift_h, sq))) return rc;
+  if ((rc = rep_apply_launch(ctx, rep_batch(cb, 2, F_BH), s0->ldm, t0, ws, d, s0->m_h, nullptr, sq))) return rc;
+  if ((rc = fh_axpby(1.0, wx, sigma_next2, ws, wx, dn, sq))) return rc;  // mean' = x + s'^2 score'
+  if ((rc = cov_fwd_b(ctx, cb, wx, mean_out, 1, sq))) return rc;
+  return cov_fwd_b(ctx, cb, ws, score_out, 1, sq);
+}
+
+// mean_x, mean_xn, x, xn, dx, de, cdx: [nimg][d] contiguous (dx, de, cdx: scratch)
+static int space_update_b(fh_context* ctx, const CovB& cb, const double* mean_x, const double* mean_xn, double s2, const double* x,
+                          const double* xn, double* dx, double* de, double* cdx, hipStream_t sq) {
+  const fh_cov_state* s0 = cb.st[0];
+  if (s0->m_c + 2 > kWbMax || s0->m_h + 2 > kWbMax) return FH_ESIZE;
+  const int mc = s0->m_c, mh = s0->m_h, nimg = cb.nimg;
+  const int64_t d = s0->d, dn = d * nimg;
+  if (s0->ldm < (s0->project ? mc : mc + 2) || s0->ldm < mh + 2) return FH_EINVAL;
+  int rc;
+  if ((rc = fh_axpby(1.0, xn, -1.0, x, dx, dn, sq))) return rc;
+  if ((rc = cov_fwd_b(ctx, cb, dx, dx, 0, sq))) return rc;
+  if ((rc = fh_axpby(1.0, mean_xn, -1.0, mean_x, de, dn, sq))) return rc;
+  if ((rc = cov_fwd_b(ctx, cb, de, de, 0, sq))) return rc;
+  const PtrTab scal = cov_tab(cb, F_SCAL);
+  if ((rc = space_prep_b(ctx, nimg, de, s2, dx, de, scal, d, sq))) return rc;  // de <- s2 dm; scal[0] = dx.de
+  // two-pass apply also on an exclusive context: the single-sweep kernel keeps c = M t in registers, and the closed-form
+  // C^-1 below reads it from ctx->coef
+  const int fused_was = ctx->fused_disabled;
+  ctx->fused_disabled = 1;
+  rc = rep_apply_launch(ctx, rep_batch(cb, 0, F_BC), s0->ldm, dx, cdx, d, mc, nullptr, sq);
+  ctx->fused_disabled = fused_was;
+  if (rc) return rc;
+  if ((rc = dot_b(ctx, nimg, cdx, dx, scal, 1, d, sq))) return rc;  // scal[1] = dx.(C dx)
+  if (!s0->project && mc > 0)  // c = M t of that apply (ctx->coef) is needed after the next dots pass overwrites it
+    hipLaunchKernelGGL(k_copy_small, dim3((unsigned)nimg), dim3(256), 0, sq, (const double*)ctx->coef, (int64_t)2 * FH_MAX_COLS,
+                       cov_tab(cb, F_G), mc);
+  const PtrTab none = tab1(nullptr);
+  hipLaunchKernelGGL(k_space_commit, dim3(512, 1, (unsigned)nimg), dim3(256), 0, sq, (const double*)de, (const double*)cdx, 0.0, 0.0,
+                     s2, cov_tab(cb, F_D, 0), cov_tab(cb, F_R, 0), s0->project ? none : cov_tab(cb, F_BC, 0, (int64_t)mc * d),
+                     s0->project ? none : cov_tab(cb, F_BC, 0, (int64_t)(mc + 1) * d), cov_tab(cb, F_D, 2), cov_tab(cb, F_R, 2),
+                     cov_tab(cb, F_BH, 0, (int64_t)mh * d), cov_tab(cb, F_BH, 0, (int64_t)(mh + 1) * d), s0->project, d, 1, scal,
+                     cov_tab(cb, F_M, 0), s0->ldm, mc, cov_tab(cb, F_M, 2), s0->ldm, mh);
+  FH_LAUNCH_CHECK();
+  const int mh2 = mh + 2;
+  if (s0->project) {
+    // the pair went into the diagonal: C^-1 over the unchanged columns by Woodbury
+    if ((rc = cov_invert_b(ctx, cb, 0, 1, F_BC, mc, 0.0, sq))) return rc;
+  } else {
+    // C^-1 in closed form (k_bfgs_inverse_commit): cC = M t saved above; s = Wi^T de and Mi s from a dots pass over the
+    // old columns with the inverse representation's row scale; de^T D^-1 de from one more reduction
+    if (mc > 0 && (rc = rep_apply_launch(ctx, rep_batch(cb, 1, F_BC), s0->ldm, de, nullptr, d, mc, nullptr, sq))) return rc;
+    hipLaunchKernelGGL(k_wnorm_partial, dim3(kDotBlocks, 1, (unsigned)nimg), dim3(256), 0, sq, (const double*)de, cov_tab(cb, F_D, 1),
+                       ctx->w2, (int64_t)kCgScratch, d);
+    hipLaunchKernelGGL(k_scalar_reduce, dim3((unsigned)nimg), dim3(256), 0, sq, (const double*)ctx->w2, (int64_t)kCgScratch,
+                       kDotBlocks, scal, 2);
+    hipLaunchKernelGGL(k_bfgs_inverse_commit, dim3((unsigned)nimg), dim3(256), 0, sq, scal, cov_tab(cb, F_G), (const double*)ctx->coef,
+                       (int64_t)2 * FH_MAX_COLS, cov_tab(cb, F_M, 1), s0->ldm, mc);
+    FH_LAUNCH_CHECK();
+  }
+  return cov_invert_b(ctx, cb, 2, 3, F_BH, mh2, 0.0, sq);  // H^-1 (its diagonal was re-derived from C: full Woodbury)
 }
 
 int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x, const double* score, double shift_c,
                        double shift_h, double sigma_next2, int only_covariance, double* wx, double* ws,
                        double* mean_out, double* score_out, void* stream) {
-  if (!ctx || !st || st->m_c > kWbMax || st->m_h > kWbMax) return !ctx || !st ? FH_EINVAL : FH_ESIZE;
-  int rc = cov_shift_forward(ctx, st, 0, 1, st->Bc, st->m_c, shift_c, stream);  // C <- (C^-1 + shift)^-1, C^-1 += shift
-  if (rc || only_covariance) return rc;
-  if (!x || !score || !wx || !ws || !mean_out || !score_out) return FH_EINVAL;
-  if ((rc = cov_fwd(ctx, st, x, wx, 0, stream))) return rc;
-  if ((rc = cov_fwd(ctx, st, score, ws, 0, stream))) return rc;
-  // t0 = H^-1 score with the OLD Hessian, then H <- (H^-1 + shift)^-1, new score = H t0
-  if ((rc = fh_rep_apply(ctx, st->D[3], st->r[3], st->Bh, st->M[3], st->ldm, ws, st->t0, st->d, st->m_h, stream))) return rc;
-  if ((rc = cov_shift_forward(ctx, st, 2, 3, st->Bh, st->m_h, shift_h, stream))) return rc;
-  if ((rc = fh_rep_apply(ctx, st->D[2], st->r[2], st->Bh, st->M[2], st->ldm, st->t0, ws, st->d, st->m_h, stream))) return rc;
-  if ((rc = fh_axpby(1.0, wx, sigma_next2, ws, wx, st->d, stream))) return rc;  // mean' = x + s'^2 score'
-  if ((rc = cov_fwd(ctx, st, wx, mean_out, 1, stream))) return rc;
-  return cov_fwd(ctx, st, ws, score_out, 1, stream);
+  if (!ctx || !st) return FH_EINVAL;
+  CovB cb;
+  cb.nimg = 1, cb.st[0] = st;
+  return time_update_b(ctx, cb, x, score, shift_c, shift_h, sigma_next2, only_covariance, wx, ws, st->t0, mean_out, score_out,
+                       (hipStream_t)stream);
 }
 
 int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* mean_x, const double* mean_xn, double s2,
                         const double* x, const double* xn, void* stream) {
   if (!ctx || !st || !mean_x || !mean_xn || !x || !xn) return FH_EINVAL;
-  if (st->m_c + 2 > kWbMax || st->m_h + 2 > kWbMax) return FH_ESIZE;
-  const int mc = st->m_c, mh = st->m_h;
-  if (st->ldm < (st->project ? mc : mc + 2) || st->ldm < mh + 2) return FH_EINVAL;
-  int rc;
-  double *dx = st->t0, *de = st->t1, *cdx = st->t2;
-  if ((rc = fh_axpby(1.0, xn, -1.0, x, dx, st->d, stream))) return rc;
-  if ((rc = cov_fwd(ctx, st, dx, dx, 0, stream))) return rc;
-  if ((rc = fh_axpby(1.0, mean_xn, -1.0, mean_x, de, st->d, stream))) return rc;
-  if ((rc = cov_fwd(ctx, st, de, de, 0, stream))) return rc;
-  if ((rc = fh_space_prep(ctx, de, s2, dx, de, st->scal, st->d, stream))) return rc;  // de <- s2 dm; scal[0] = dx.de
-  // two-pass apply also on an exclusive context: the single-sweep kernel keeps c = M t in registers, and the closed-form
-  // C^-1 below reads it from ctx->coef
-  const int fused_was = ctx->fused_disabled;
-  ctx->fused_disabled = 1;
-  rc = fh_rep_apply(ctx, st->D[0], st->r[0], st->Bc, st->M[0], st->ldm, dx, cdx, st->d, mc, stream);
-  ctx->fused_disabled = fused_was;
+  CovB cb;
+  cb.nimg = 1, cb.st[0] = st;
+  return space_update_b(ctx, cb, mean_x, mean_xn, s2, x, xn, st->t0, st->t1, st->t2, (hipStream_t)stream);
+}
+
+int fh_cov_time_update_batched(fh_context* ctx, int nimg, const fh_cov_state* sts, const double* x, const double* score,
+                               double shift_c, double shift_h, double sigma_next2, double* work, double* mean_out,
+                               double* score_out, void* stream) {
+  if (!ctx || !sts || !x || !score || !work || !mean_out || !score_out || nimg < 1 || nimg > FH_MAX_BATCH) return FH_EINVAL;
+  CovB cb;
+  cb.nimg = nimg;
+  for (int i = 0; i < nimg; ++i) cb.st[i] = sts + i;
+  int rc = cov_batch_check(ctx, cb);
   if (rc) return rc;
-  if ((rc = fh_dot(ctx, cdx, dx, st->scal, 1, st->d, stream))) return rc;              // scal[1] = dx.(C dx)
-  if (!st->project && mc > 0)  // c = M t of that apply (ctx->coef) is needed after the next dots pass overwrites it
-    hipLaunchKernelGGL(k_copy_small, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ctx->coef, st->G, mc);
-  double* bc0 = st->project ? nullptr : st->Bc + (int64_t)mc * st->d;
-  double* bc1 = st->project ? nullptr : st->Bc + (int64_t)(mc + 1) * st->d;
-  if ((rc = fh_space_commit_dev(ctx, de, cdx, st->scal, s2, st->D[0], st->r[0], bc0, bc1, st->D[2], st->r[2],
-                                st->Bh + (int64_t)mh * st->d, st->Bh + (int64_t)(mh + 1) * st->d, st->M[0], st->ldm, mc,
-                                st->M[2], st->ldm, mh, st->project, st->d, stream)))
-    return rc;
-  const int mh2 = mh + 2;
-  if (st->project) {
-    // the pair went into the diagonal: C^-1 over the unchanged columns by Woodbury
-    if ((rc = cov_invert(ctx, st, 0, 1, st->Bc, mc, 0.0, stream))) return rc;
-  } else {
-    // C^-1 in closed form (k_bfgs_inverse_commit): cC = M t saved above; s = Wi^T de and Mi s from a dots pass over the
-    // old columns with the inverse representation's row scale; de^T D^-1 de from one more reduction
-    hipStream_t sq = (hipStream_t)stream;
-    if (mc > 0) {
-      fh_batch per;
-      memset(&per, 0, sizeof(per));
-      per.nimg = 1;
-      per.D[0] = st->D[1], per.r[0] = st->r[1], per.B[0] = st->Bc, per.M[0] = st->M[1];
-      if ((rc = rep_apply_launch(ctx, per, st->ldm, de, nullptr, st->d, mc, nullptr, sq))) return rc;
-    }
-    hipLaunchKernelGGL(k_wnorm_partial, dim3(kDotBlocks), dim3(256), 0, sq, (const double*)de, (const double*)st->D[1],
-                       ctx->w2, st->d);
-    hipLaunchKernelGGL(k_scalar_reduce, dim3(1), dim3(256), 0, sq, (const double*)ctx->w2, kDotBlocks, st->scal + 2);
-    hipLaunchKernelGGL(k_bfgs_inverse_commit, dim3(1), dim3(256), 0, sq, (const double*)st->scal, (const double*)st->G,
-                       (const double*)(ctx->coef + FH_MAX_COLS), (const double*)ctx->coef, st->M[1], st->ldm, mc);
-    FH_LAUNCH_CHECK();
-  }
-  return cov_invert(ctx, st, 2, 3, st->Bh, mh2, 0.0, stream);  // H^-1 (its diagonal was re-derived from C: full Woodbury)
+  const int64_t dn = sts[0].d * nimg;
+  return time_update_b(ctx, cb, x, score, shift_c, shift_h, sigma_next2, 0, work, work + dn, work + 2 * dn, mean_out, score_out,
+                       (hipStream_t)stream);
+}
+
+int fh_cov_space_update_batched(fh_context* ctx, int nimg, const fh_cov_state* sts, const double* mean_x, const double* mean_xn,
+                                double s2, const double* x, const double* xn, double* work, void* stream) {
+  if (!ctx || !sts || !mean_x || !mean_xn || !x || !xn || !work || nimg < 1 || nimg > FH_MAX_BATCH) return FH_EINVAL;
+  CovB cb;
+  cb.nimg = nimg;
+  for (int i = 0; i < nimg; ++i) cb.st[i] = sts + i;
+  int rc = cov_batch_check(ctx, cb);
+  if (rc) return rc;
+  const int64_t dn = sts[0].d * nimg;
+  return space_update_b(ctx, cb, mean_x, mean_xn, s2, x, xn, work, work + dn, work + 2 * dn, (hipStream_t)stream);
 }
 
 int fh_read_scalars(fh_context* ctx, const double* scal, double* out_host, int k, void* stream) {

@@ -138,6 +138,9 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
         raise NotImplementedError("only the 'edm' discretisation with sigma(t)=t, s(t)=1 is on the Free Hunch path")
     if o.get("S_churn", 0) != 0:
         raise NotImplementedError("the lock-step sampler is deterministic (S_churn = 0); use conditional_sampler")
+    import os as _os
+    import time as _time
+    _t_mech = _time.perf_counter()
     mechs = []
     for b in range(B):
         assert getattr(operators[b], "ctx_slot", 0) == slot_base + b, "every concurrent image needs its own ctx_slot"
@@ -172,9 +175,11 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             main.wait_event(done)
         return [r[0] for r in res]
 
-    import os as _os
-    import time as _time
     prof = {"fwd": 0.0, "update": 0.0, "solve": 0.0, "vjp": 0.0, "finish": 0.0} if _os.environ.get("FH_PHASE_TIMES") else None
+    if prof is not None:
+        torch.cuda.synchronize()
+        prof["mechanisms"] = _time.perf_counter() - _t_mech
+        _t_loop = _time.perf_counter()
 
     # Host <-> device rendezvous after the two UNet passes.  Nothing needs it for correctness (the streams are ordered by
     # events); measured on MI355X it is worth ~5 % of a batch: with the host hundreds of launches ahead, the per-image
@@ -188,6 +193,8 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             prof[name] += _time.perf_counter() - t0
         return _time.perf_counter()
 
+    hist = {"x": None, "m": None}  # the previous call's x_t and denoiser output of the whole batch (contiguous [B,3,S,S])
+
     def guidance(x, t):
         sigma = torch.tensor(t, dtype=torch.float64, device=dev)
         t0 = _tick("finish", _time.perf_counter()) if (prof is not None or sync_after) else 0.0
@@ -200,12 +207,18 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
             # covariance updates per image on their own streams, then ONE kernel sequence solves all B systems.
             # `not torch.allclose(x, x_prev)` (:250) of all images with one device -> host transfer
             changed = [None] * B
+            prev, prev_m = hist["x"], hist["m"]
             if all(len(mm.xs) != 0 for mm in mechs):
-                prev = torch.cat([mm.xs[-1] for mm in mechs], 0)
+                if prev is None:
+                    prev = torch.cat([mm.xs[-1] for mm in mechs], 0)
                 close = ((x_det - prev).abs() <= 1e-8 + 1e-5 * prev.abs()).reshape(B, -1).all(dim=1)  # allclose's rule
                 changed = [not c for c in close.tolist()]
-            fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net, x_changed=changed[b]),
-                               x_det[b:b + 1])[1])
+            # one kernel sequence updates the covariance of all B images (same kernels with the image as a grid dimension);
+            # per-image streams only when the batch does not qualify (different column counts, truncation, ...)
+            if not (hasattr(mechs[0], "fh_update_batched") and type(mechs[0]).fh_update_batched(
+                    mechs, x_det, m_det, sigma, prev, prev_m, changed if changed[0] is not None else None, slot=slot_base)):
+                fan_out(lambda b: (mechs[b].fh_update(x_det[b:b + 1], m_det[b:b + 1], sigma, net, x_changed=changed[b]),
+                                   x_det[b:b + 1])[1])
             t0 = _tick("update", t0)
             infos = []
             mats = solve_customcuda_batched(operators, ys, [m_det[b:b + 1] for b in range(B)],
@@ -215,6 +228,7 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
                 mechs[b]._rec = dict(infos[b])
         else:
             mats = torch.cat(fan_out(lambda b: mechs[b].fh_solve(x_det[b:b + 1], m_det[b:b + 1], ys[b], sigma, net)), 0)
+        hist["x"], hist["m"] = x_det, m_det
         t0 = _tick("solve", t0)
         (g,) = torch.autograd.grad((mats * x0_mean).sum(), x_t)
         t0 = _tick("vjp", t0)
@@ -258,6 +272,8 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
         from . import _lib
         _lib.Context.get(noise.shape[-1], 3 * B, 0, slot=5000 + 64 * slot_base + B).status()
     if prof is not None:
+        torch.cuda.synchronize()
+        prof["loop_total"] = _time.perf_counter() - _t_loop
         print("[FH_PHASE_TIMES] seconds per batch:", {k: round(v, 3) for k, v in prof.items()}, flush=True)
     conditional_sampler_batched.last_mechanisms = mechs
     conditional_sampler_batched.tls.mechanisms = mechs  # per host thread (several groups may run concurrently)

@@ -135,6 +135,20 @@ int fh_cov_time_update(fh_context* ctx, const fh_cov_state* st, const double* x,
 int fh_cov_space_update(fh_context* ctx, const fh_cov_state* st, const double* mean_x, const double* mean_xn, double s2,
                         const double* x, const double* xn, void* stream);
 
+/* The same two updates for the nimg images of a lock-step batch in ONE launch sequence (the reference asserts batch 1,
+ * online_update_bfgs.py:161,255, and loops over images; BASELINE configs[1] advances 8 images together): the kernels of the
+ * single-image entry points with the image as a grid dimension and per-image pointer tables, so an image's result is
+ * bitwise the one fh_cov_time_update / fh_cov_space_update give it.  `sts`: nimg states that agree on d, m_c, m_h, ldm, ldg,
+ * project, use_dct (else FH_EINVAL; the caller then updates image by image); their t0 / t1 / t2 are not used.
+ * x, score, mean_out, score_out, mean_x, mean_xn, xn: [nimg][d] contiguous; work: 3 x [nimg][d] of scratch.
+ * `ctx`: a context created with planes_max >= 3 nimg and m_cap >= 1 (Gram scratch for every image of the batch). */
+int fh_cov_time_update_batched(fh_context* ctx, int nimg, const fh_cov_state* sts, const double* x, const double* score,
+                               double shift_c, double shift_h, double sigma_next2, double* work, double* mean_out,
+                               double* score_out, void* stream);
+int fh_cov_space_update_batched(fh_context* ctx, int nimg, const fh_cov_state* sts, const double* mean_x,
+                                const double* mean_xn, double s2, const double* x, const double* xn, double* work,
+                                void* stream);
+
 /* The m x m algebra of the Woodbury step above on the device (m <= 64; FH_ESIZE beyond, the caller then uses its host
  * path):  Mdst[:m,:m] = sym( -Msrc (I + G Msrc)^-1 ), Gauss-Jordan with partial pivoting in one workgroup.
  * Replaces the D2H copy + numpy.linalg.inv + H2D copy of an update, so that update_time_step / update_space_step

@@ -41,6 +41,17 @@ def gauss_prior_denoise(x, sigma, var=GAUSS_PRIOR_VAR):
     return x * (var / (var + sigma ** 2))
 
 
+def pp_prior_var(size, seed=77):
+    """A smooth, strictly positive per-pixel prior variance in [0.05, 0.5] (for the per-pixel-variance plugins)."""
+    return 0.05 + 0.45 * (smooth_image(size, seed).double() + 1.0) / 2.0
+
+
+def pp_gauss_prior_denoise(x, sigma, var):
+    """Posterior mean of independent N(0, var[p]) priors: diagonal Jacobian var / (var + sigma^2) > 0, so TMPD's variance
+    field (Jacobian row sums x sigma^2) is positive and spatially varying."""
+    return x * (var / (var + sigma ** 2))
+
+
 def damped_state(seeded_state, cfg, seed, damp=DAMP):
     """`seeded_state` weights with the last convolution (out.2) scaled by `damp`: F = UNet(c_in x) stays small, so the
     denoiser D = clamp(x - sigma F) has a Jacobian close to the clamp mask and the sampler does not amplify the 1e-5

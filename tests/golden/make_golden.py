@@ -83,7 +83,7 @@ from training.openai_util import create_model  # noqa: E402
 
 from oracle.unet_oracle import UNetConfig, seeded_state  # noqa: E402  (weights recipe + config only)
 sys.path.insert(0, HERE)
-from inputs import damped_state, gauss_prior_denoise, SMALL_A, SMALL_B, SMALL_C, solver256_measurement, dense_case, dense_chain, randn, rng, script as _script, smooth_image  # noqa: E402
+from inputs import damped_state, gauss_prior_denoise, pp_gauss_prior_denoise, pp_prior_var, SMALL_A, SMALL_B, SMALL_C, solver256_measurement, dense_case, dense_chain, randn, rng, script as _script, smooth_image  # noqa: E402
 
 F64 = torch.float64
 
@@ -128,6 +128,22 @@ class GaussPriorNet(iDDPMLinearPrecond):
 
     def forward(self, x, sigma, **kw):
         return gauss_prior_denoise(x, sigma.to(torch.double).reshape(-1, 1, 1, 1)), None
+
+
+class PerPixelGaussPriorNet(iDDPMLinearPrecond):
+    """inputs.pp_gauss_prior_denoise (independent N(0, var[p]) priors) behind the reference's precond interface."""
+
+    def __init__(self, size):
+        super().__init__(None, size, 3)
+        self.register_buffer("var", pp_prior_var(size))
+
+    def forward(self, x, sigma, **kw):
+        return pp_gauss_prior_denoise(x, sigma.to(torch.double).reshape(-1, 1, 1, 1), self.var), None
+
+
+def _standin_net(kind, size, cfg, seed):
+    return {"gauss": lambda: GaussPriorNet(size), "ppgauss": lambda: PerPixelGaussPriorNet(size),
+            "damped": lambda: damped_net(cfg, seed)}[kind]()
 
 
 def damped_net(cfg, seed):
@@ -593,7 +609,7 @@ def gold_traj(size=64, cfg=SMALL_A, unet_seed=11, cases=TRAJ_CASES_64, seed_base
         tag, opname, solver, nsteps, over = case[:5]
         kind = case[5] if len(case) > 5 else "unet"  # "gauss": closed-form Gaussian-prior denoiser, "damped": damped UNet
         if kind not in nets:
-            nets[kind] = GaussPriorNet(size) if kind == "gauss" else damped_net(cfg, unet_seed)
+            nets[kind] = _standin_net(kind, size, cfg, unet_seed)
         net = nets[kind]
         x0 = smooth_image(size, seed_base + ci)
         noise = randn((1, 3, size, size), seed_base + 10 + ci, torch.float32)
@@ -716,7 +732,7 @@ def gold_baselines(cases=None, name="baselines", seed_base=140):
             tag, mech, opname, solver, nsteps, over = case[:6]
             kind = case[6] if len(case) > 6 else "unet"
             if kind not in nets:
-                nets[kind] = GaussPriorNet(size) if kind == "gauss" else damped_net(SMALL_A, 11)
+                nets[kind] = _standin_net(kind, size, SMALL_A, 11)
             net = nets[kind]
             x0 = smooth_image(size, seed_base + ci)
             noise = randn((1, 3, size, size), seed_base + 10 + ci, torch.float32)
@@ -751,12 +767,14 @@ def gold_perpixel():
 
 
 # TMPD with a well-posed variance field (the random-weight UNet of PERPIXEL_CASES gives Jacobian row sums of both signs, an
-# indefinite system from call 1 on): the Gaussian-prior denoiser (constant positive field) and the damped UNet (row sums
-# = clamp mask x (1 - small) >= 0)
+# indefinite system from call 1 on - and so does any UNet behind the precond's clamp: a clamped pixel contributes
+# -sigma c_in sum_j dF_j/dx_i of either sign): closed-form Gaussian-prior denoisers, a constant positive field ("gauss") and a
+# spatially varying one ("ppgauss", inputs.pp_prior_var)
 TMPD_POS_CASES = [
     ("tmpd_gb_gauss", "tmpd", "gaussian_blur", "heun", 8, {"clip_x0_mean": True}, "gauss"),
-    ("tmpd_ip_damped", "tmpd", "inpainting", "euler", 10, {"clip_x0_mean": True}, "damped"),
-    ("tmpd_sr_damped", "tmpd", "super_resolution", "heun", 6, {"clip_x0_mean": True}, "damped"),
+    ("tmpd_ip_ppgauss", "tmpd", "inpainting", "euler", 10, {"clip_x0_mean": True}, "ppgauss"),
+    ("tmpd_sr_ppgauss", "tmpd", "super_resolution", "heun", 6, {"clip_x0_mean": True}, "ppgauss"),
+    ("tmpd_gb_ppgauss", "tmpd", "gaussian_blur", "euler", 8, {"clip_x0_mean": True}, "ppgauss"),
 ]
 
 

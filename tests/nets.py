@@ -23,6 +23,22 @@ def gauss_net(size, dev):
     return GaussPriorNet().to(dev)
 
 
+def pp_gauss_net(size, dev):
+    """inputs.pp_gauss_prior_denoise (per-pixel prior variance inputs.pp_prior_var) behind the product's precond interface."""
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+
+    class PerPixelGaussPriorNet(iDDPMLinearPrecond):
+        def __init__(self):
+            super().__init__(None, size, 3)
+            self.register_buffer("var", inputs.pp_prior_var(size))
+
+        def forward(self, x, sigma, **kw):
+            sigma = torch.as_tensor(sigma, device=x.device).to(torch.double).reshape(-1, 1, 1, 1)
+            return inputs.pp_gauss_prior_denoise(x, sigma, self.var), None
+
+    return PerPixelGaussPriorNet().to(dev)
+
+
 def _hip_cfg(cfg_in):
     from free_hunch_amd import unet as hu
     return hu.UNetConfig(**{k: getattr(cfg_in, k) for k in
@@ -31,13 +47,13 @@ def _hip_cfg(cfg_in):
                              "resblock_updown", "use_new_attention_order")})
 
 
-def damped_hip_net(cfg_in, seed, dev):
+def damped_hip_net(cfg_in, seed, dev, damp=inputs.DAMP):
     """The HIP UNet with inputs.damped_state weights (the recording side: make_golden.damped_net)."""
     from free_hunch_amd import unet as hu
     from free_hunch_amd.precond import iDDPMLinearPrecond
     cfg = _hip_cfg(cfg_in)
     model = hu.UNetModel(cfg, backend=os.environ.get("FH_UNET_BACKEND", "hip"))
-    model.load_state_dict(inputs.damped_state(hu.seeded_state, cfg, seed))
+    model.load_state_dict(inputs.damped_state(hu.seeded_state, cfg, seed, damp))
     return iDDPMLinearPrecond(model.to(dev).eval(), cfg.image_size, 3).to(dev)
 
 

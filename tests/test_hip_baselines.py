@@ -198,13 +198,14 @@ def test_online_covariance_customscipy_vs_reference_golden(dev, gold, tag, tmp_p
     assert err < 1e-3, err  # tol 1e-4 solves on the well-conditioned SR system: north-star tolerance on the final image
 
 
-@pytest.mark.parametrize("tag", ["tmpd_gb_gauss", "tmpd_ip_damped", "tmpd_sr_damped"])
+@pytest.mark.parametrize("tag", ["tmpd_gb_gauss", "tmpd_ip_ppgauss", "tmpd_sr_ppgauss", "tmpd_gb_ppgauss"])
 def test_tmpd_positive_variance_field_vs_reference_golden(dev, gold, tag, tmp_path):
     """TMPD (conditioning_mechanisms.py:112-133 with the scipy solvers :360-381, :463-484, :616-639) on EVERY call: the
-    recordings of baselines_tmpd_pos.npz use denoisers whose Jacobian row sums are non-negative - the closed-form
-    Gaussian-prior denoiser (a constant positive field) and the UNet with a damped output layer (clamp mask x (1 - small)) -
-    so sigma_y^2 I + A diag(theta) A^T is positive definite and the solve is a property of the system (with the random-weight
-    UNet of baselines_perpixel.npz it is indefinite from the second call on, see above).  The reference solves in float32
+    recordings of baselines_tmpd_pos.npz use denoisers whose Jacobian row sums are positive - closed-form Gaussian-prior
+    denoisers with a constant (`gauss`) and a spatially varying per-pixel (`ppgauss`) prior variance - so
+    sigma_y^2 I + A diag(theta) A^T is positive definite and the solve is a property of the system.  (With any UNet behind
+    the precond's clamp it is indefinite from the second call on: a clamped pixel contributes -sigma c_in sum_j dF_j/dx_i of
+    either sign - half the entries of the recorded random-weight field are negative, see above.)  The reference solves in float32
     scipy CG at tol = rtol_func_2(sigma) (1e-4 .. 1); here the float64 device CG in scipy's iteration semantics.  Asserted:
     every call's estimate checksum and the final image (north-star 1e-3)."""
     import nets
@@ -213,7 +214,7 @@ def test_tmpd_positive_variance_field_vs_reference_golden(dev, gold, tag, tmp_pa
     g = gold("baselines_tmpd_pos")
     c = baseline_inputs(g, tag)
     kind = str(g[c["p"] + "net"])
-    net = nets.gauss_net(64, dev) if kind == "gauss" else nets.damped_hip_net(inputs.SMALL_A, int(g["unet_seed"]), dev)
+    net = nets.gauss_net(64, dev) if kind == "gauss" else nets.pp_gauss_net(64, dev)
     mask = torch.from_numpy(g[c["p"] + "mask"]).float().repeat(1, 3, 1, 1) if c["opname"] == "inpainting" else None
     op = _hip_op(c["opname"], 64, dev, mask)
     kw = _base_kwargs(tmp_path, {"conditioning_mechanism": c["mech"], "diffpir_lambda": 10.0, "pigdm_posthoc_scaling": False,

