@@ -39,6 +39,10 @@ class FhCovState(C.Structure):
                 ("Bc", c_dp), ("Bh", c_dp), ("G", c_dp), ("scal", c_dp), ("t0", c_dp), ("t1", c_dp), ("t2", c_dp)]
 
 
+class FhGnEpilogue(C.Structure):
+    _fields_ = [("partial", c_dp), ("x", c_dp), ("tab", c_dp), ("mode", C.c_int32), ("act", C.c_int32)]
+
+
 class FhCgInfo(C.Structure):
     _fields_ = [("niter", C.c_int32), ("optimal", C.c_int32), ("residual_norm", C.c_double),
                 ("b_norm", C.c_double)]
@@ -81,11 +85,19 @@ _SIGS = {
                         C.c_void_p], C.c_int),
     "fh_conv2d_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
     "fh_conv2d_x6_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_void_p], C.c_int),
+    "fh_conv2d_x6_nhwc_gn": ([c_dp, c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.POINTER(FhGnEpilogue), C.c_void_p],
+                             C.c_int),
+    "fh_conv2d_x6_gn_chunks": ([C.c_int] * 10, C.c_int),
+    "fh_groupnorm_finalize": ([c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p], C.c_int),
+    "fh_groupnorm_bwd_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "fh_groupnorm_bwd_apply": ([c_dp] * 8 + [C.c_int, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
     "fh_unet_set_precision": ([C.c_int], C.c_int),
     "fh_groupnorm_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_conv2d_x6_norm_supported": ([C.c_int] * 5, C.c_int),
     "fh_conv2d_x6_norm_nhwc": ([c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
+    "fh_conv2d_x6_norm_nhwc_gn": ([c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5
+                                  + [C.POINTER(FhGnEpilogue), C.c_void_p], C.c_int),
     "fh_conv3x3_thin_nhwc": ([c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_conv3x3_wino_nhwc": ([c_dp, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_bgemm_f32": ([c_dp, c_dp, c_dp] + [C.c_int] * 10 + [C.c_int64] * 6 + [C.c_float, C.c_void_p], C.c_int),

@@ -23,7 +23,7 @@ import torch
 from torch.autograd import grad
 
 from . import _lib
-from .covariance import CovarianceHessianBFGS, CovarianceHessianBFGSDCT, ScalarCovariance
+from .covariance import CovarianceHessianBFGS, CovarianceHessianBFGSDCT, ScalarCovariance, _load_cached
 
 F64 = torch.float64
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -286,7 +286,7 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             raise ValueError("solver_type=scipy solves with a scalar / per-pixel variance; online_covariance needs "
                              "customcuda or customscipy")
         # the reference loads this file unconditionally (:225-226)
-        self.recon_mse = torch.load(os.path.join(_DATA, "recon_mse.pt"), weights_only=True)
+        self.recon_mse = _load_cached(os.path.join(_DATA, "recon_mse.pt"))
         self.mle_sigma_thres = 0.2
         self.trace = []  # per call: niter, branch, k (not in the reference; used by the parity tests)
 

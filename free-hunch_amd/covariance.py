@@ -538,6 +538,19 @@ class CovarianceHessianBFGS:
         return tuple(out)
 
 
+_FILE_CACHE = {}
+
+
+def _load_cached(path):
+    """torch.load(weights_only=True) of a small data file, once per (path, modification time): the plugin is constructed per
+    image (generate_conditional.py:120-128) and re-reading the prior variance 8 x per batch costs more than the guidance
+    call it precedes."""
+    key = (os.path.abspath(path), os.path.getmtime(path))
+    if key not in _FILE_CACHE:
+        _FILE_CACHE[key] = torch.load(path, weights_only=True)
+    return _FILE_CACHE[key]
+
+
 def _lib_max_cols():
     return 128  # column capacity of a context (Gram scratch grows with its square); Euler-100 needs 56
 
@@ -551,7 +564,7 @@ class CovarianceHessianBFGSDCT(CovarianceHessianBFGS):
     def __init__(self, data_dir, init_noise_variance, data_dim, dtype=None, max_vector_count=None, **kwargs):
         use_info = kwargs.pop("use_precalculated_info")
         if use_info:
-            var = torch.load(os.path.join(data_dir, "dct_variance.pt"), weights_only=True).reshape(-1)
+            var = _load_cached(os.path.join(data_dir, "dct_variance.pt")).reshape(-1)
             if var.numel() != data_dim:
                 raise ValueError(f"dct_variance.pt has {var.numel()} entries, data_dim is {data_dim}")
         else:

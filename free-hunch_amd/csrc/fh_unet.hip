@@ -200,9 +200,68 @@ struct ConvArgsX {
   int N, H, W, Cin, Cout, KH, KW, pad, stride, Ho, Wo;
   int ksplit;
   float* ws;
+  // optional group-sum epilogue (fh_gn_epilogue): per-(image, GroupNorm group) sums of the output tile as block partials
+  double* gn_partial;   // [N][gn_chunks][32][2] or null
+  const float* gn_x;    // mode 1: forward input of the GroupNorm whose backward consumes this output
+  const float* gn_tab;  // mode 1: [N][5][Cout]  A, Bc, mean, rstd, gamma (1 + scale)
+  int gn_mode, gn_act, gn_chunks;
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+
+// Group-sum epilogue of the split-bf16 convolutions.  A lane of the 32 x 32 MFMA layout holds 16 rows x MI tiles of ONE output
+// channel per column tile j, so the sums of a channel are formed in registers (double), the two lane halves are folded with a
+// shuffle, every wave leaves its 32 x NI channel sums in LDS and 64 threads add them per (group, which) in a FIXED order
+// (deterministic) and write the block's partial: the statistics pass of the consuming GroupNorm (mode 0: sum v, sum v^2) or the
+// two sums of its backward (mode 1: sum g, sum g xhat with g = dy act'(t) gamma (1 + scale)) never read the tensor again.
+struct GnAcc {
+  double s0, s1;
+};
+__device__ __forceinline__ void gn_accum(const ConvArgsX& a, GnAcc& g, float v, int64_t row, int co, const float (&tb)[5]) {
+  if (a.gn_mode == 0) {
+    g.s0 += v;
+    g.s1 += (double)v * v;
+  } else {
+    const float x = a.gn_x[row * a.Cout + co];
+    const float t = fmaf(x, tb[0], tb[1]);
+    const float xh = (x - tb[2]) * tb[3];
+    float gg = v;
+    if (a.gn_act) {
+      const float sg = 1.f / (1.f + __expf(-t));
+      gg *= sg * (1.f + t * (1.f - sg));
+    }
+    gg *= tb[4];
+    g.s0 += gg;
+    g.s1 += (double)gg * xh;
+  }
+}
+template <int NI, int WM, int WN, int BN>
+__device__ __forceinline__ void gn_reduce(const ConvArgsX& a, const GnAcc (&g)[NI], double* gred, int n, int chunk, int n0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const double s0 = g[j].s0 + __shfl_xor(g[j].s0, 32, 64);
+    const double s1 = g[j].s1 + __shfl_xor(g[j].s1, 32, 64);
+    if (lane < 32) {
+      gred[((wave * 32 + lr) * NI + j) * 2 + 0] = s0;
+      gred[((wave * 32 + lr) * NI + j) * 2 + 1] = s1;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int G = tid >> 1, which = tid & 1, cg = a.Cout / 32;
+    int c0 = G * cg, c1 = c0 + cg;
+    c0 = c0 < n0 ? n0 : c0;
+    c1 = c1 > n0 + BN ? n0 + BN : c1;
+    c1 = c1 > a.Cout ? a.Cout : c1;
+    double sum = 0.0;
+    for (int c = c0; c < c1; ++c) {
+      const int cl = c - n0, wn_i = cl / (NI * 32), j = (cl % (NI * 32)) / 32, l = cl % 32;
+      for (int wm_i = 0; wm_i < WM; ++wm_i) sum += gred[(((wm_i * WN + wn_i) * 32 + l) * NI + j) * 2 + which];
+    }
+    a.gn_partial[((int64_t)n * a.gn_chunks + chunk) * 64 + tid] = sum;
+  }
+}
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -371,12 +430,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
     }
   }
 
+  __shared__ double gred[WM * WN * 32 * NI * 2];
+  const bool gn = a.gn_partial != nullptr;  // (host: only with ksplit == 1 and tiles that lie inside one image)
+  const int gn_n = gn ? (int)(m0 / ((int64_t)a.Ho * a.Wo)) : 0;
+  GnAcc gsum[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
+    gsum[j].s0 = gsum[j].s1 = 0.0;
     const int co = n0 + wn + j * 32 + lr;
     if (co >= a.Cout) continue;
     const float bv = (a.bias != nullptr && a.ksplit == 1) ? a.bias[co] : 0.f;
     float* dst = a.ksplit == 1 ? a.out : a.ws + (int64_t)blockIdx.z * M * a.Cout;
+    float tb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (gn && a.gn_mode == 1) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) tb[q] = a.gn_tab[((int64_t)gn_n * 5 + q) * a.Cout + co];
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -386,9 +455,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
           float v = acc[i][j][r] + bv;
           if (a.res != nullptr && a.ksplit == 1) v += a.res[row * a.Cout + co];
           dst[row * a.Cout + co] = v;
+          if (gn) gn_accum(a, gsum[j], v, row, co, tb);
         }
       }
     }
+  }
+  if (gn) {
+    const int tiles_per_img = (int)(((int64_t)a.Ho * a.Wo) / BM);
+    gn_reduce<NI, WM, WN, BN>(a, gsum, gred, gn_n, (tile_m % tiles_per_img) * (int)gridDim.y + tile_n, n0);
   }
 }
 
@@ -584,11 +658,20 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
     }
   }
   const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
+  __shared__ double gred[(BM / 64) * WN * 32 * NI * 2];
+  const bool gn = a.gn_partial != nullptr;
+  GnAcc gsum[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
+    gsum[j].s0 = gsum[j].s1 = 0.0;
     const int co = n0 + wn + j * 32 + lr;
     if (co >= a.Cout) continue;
     const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
+    float tb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (gn && a.gn_mode == 1) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) tb[q] = a.gn_tab[((int64_t)pn * 5 + q) * a.Cout + co];
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -598,10 +681,12 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
           float v = acc[i][j][r] + bv;
           if (a.res != nullptr) v += a.res[row * a.Cout + co];
           a.out[row * a.Cout + co] = v;
+          if (gn) gn_accum(a, gsum[j], v, row, co, tb);
         }
       }
     }
   }
+  if (gn) gn_reduce<NI, BM / 64, WN, BN>(a, gsum, gred, pn, (rem / BM) * (int)gridDim.y + tile_n, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,14 +1406,69 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
   return 0;
 }
 
+// tile height (pixels) of the launch fh_conv2d_x6_nhwc takes for this layer, 0 when the group-sum epilogue does not apply
+// (split-K, the 64-column tile, output tiles that straddle two images, channels not a multiple of 32)
+static int x6_gn_tile(int ksplit, int64_t M, int HoWo, int Ho, int Wo, int Cout, int KH, int KW, int pad, int stride) {
+  if (ksplit != 1 || Cout <= 64 || Cout % 32 != 0) return 0;
+  const int64_t b128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+  int bm = 0;
+  if (b128 >= 384) {
+    const bool r3 = !getenv("FH_X6_NOREUSE") && KH == 3 && KW == 3 && pad == 1 && stride == 1 && M % 128 == 0;
+    const bool big = r3 && !getenv("FH_X6_NOBIG") && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
+    if (big && (Wo % 256 == 0 || (Wo == 128 && Ho % 2 == 0) || (Wo == 64 && Ho % 4 == 0)))
+      bm = 256;
+    else
+      bm = 128;
+  } else if (((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
+    bm = 64;
+  }
+  return (bm > 0 && HoWo % bm == 0) ? bm : 0;
+}
+
+static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                          int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                          const fh_gn_epilogue* epi, void* stream);
+
 int fh_conv2d_x6_nhwc(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
                       int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
                       void* stream) {
+  return conv2d_x6_impl(in, wx, bias, res, out, ws, ksplit, N, H, W, Cin, Cout, KH, KW, pad, stride, nullptr, stream);
+}
+
+int fh_conv2d_x6_nhwc_gn(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                         int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                         const fh_gn_epilogue* epi, void* stream) {
+  return conv2d_x6_impl(in, wx, bias, res, out, ws, ksplit, N, H, W, Cin, Cout, KH, KW, pad, stride, epi, stream);
+}
+
+int fh_conv2d_x6_gn_chunks(int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride) {
+  if (N < 1 || H < 1 || W < 1 || Cout < 1 || stride < 1) return 0;
+  const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const int bm = x6_gn_tile(ksplit, (int64_t)N * Ho * Wo, Ho * Wo, Ho, Wo, Cout, KH, KW, pad, stride);
+  return bm ? (Ho * Wo / bm) * ((Cout + 127) / 128) : 0;
+}
+
+static int set_gn(ConvArgsX& a, const fh_gn_epilogue* epi, int chunks) {
+  a.gn_partial = nullptr, a.gn_x = nullptr, a.gn_tab = nullptr, a.gn_mode = a.gn_act = a.gn_chunks = 0;
+  if (epi == nullptr || epi->partial == nullptr) return 0;
+  if (chunks <= 0 || epi->mode < 0 || epi->mode > 1 || (epi->mode == 1 && (!epi->x || !epi->tab))) return FH_EINVAL;
+  a.gn_partial = epi->partial, a.gn_x = epi->x, a.gn_tab = epi->tab;
+  a.gn_mode = epi->mode, a.gn_act = epi->act, a.gn_chunks = chunks;
+  return 0;
+}
+
+static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                          int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                          const fh_gn_epilogue* epi, void* stream) {
   if (!in || !wx || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
     return FH_EINVAL;
   if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
   ConvArgsX a;
   a.ab = nullptr, a.act = 0;
+  {
+    const int rc = set_gn(a, epi, fh_conv2d_x6_gn_chunks(ksplit, N, H, W, Cin, Cout, KH, KW, pad, stride));
+    if (rc) return rc;
+  }
   a.in = in, a.wx = (const __bf16*)wx, a.bias = bias, a.res = res, a.out = out;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
   a.Ho = (H + 2 * pad - KH) / stride + 1;
@@ -1411,11 +1551,32 @@ int fh_conv2d_x6_norm_supported(int N, int H, int W, int Cin, int Cout) {
   return (W % 128 == 0) || (W == 64 && H % 2 == 0) || (W == 32 && H % 4 == 0);
 }
 
+static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                               const float* res, float* out, int N, int H, int W, int Cin, int Cout, const fh_gn_epilogue* epi,
+                               void* stream);
+
 int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
                            const float* res, float* out, int N, int H, int W, int Cin, int Cout, void* stream) {
+  return conv2d_x6_norm_impl(in, ab_table, act, wx, bias, res, out, N, H, W, Cin, Cout, nullptr, stream);
+}
+
+int fh_conv2d_x6_norm_nhwc_gn(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                              const float* res, float* out, int N, int H, int W, int Cin, int Cout, const fh_gn_epilogue* epi,
+                              void* stream) {
+  return conv2d_x6_norm_impl(in, ab_table, act, wx, bias, res, out, N, H, W, Cin, Cout, epi, stream);
+}
+
+static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                               const float* res, float* out, int N, int H, int W, int Cin, int Cout, const fh_gn_epilogue* epi,
+                               void* stream) {
   if (!in || !ab_table || !wx || !out || !fh_conv2d_x6_norm_supported(N, H, W, Cin, Cout)) return FH_EINVAL;
   ConvArgsX a;
   a.ab = ab_table, a.act = act;
+  {
+    // the fused-input kernel takes the same tile as the plain 3 x 3 / stride 1 / pad 1 launch of the layer
+    const int rc = set_gn(a, epi, fh_conv2d_x6_gn_chunks(1, N, H, W, Cin, Cout, 3, 3, 1, 1));
+    if (rc) return rc;
+  }
   a.in = in, a.wx = (const __bf16*)wx, a.bias = bias, a.res = res, a.out = out;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = 3, a.KW = 3, a.pad = 1, a.stride = 1;
   a.Ho = H, a.Wo = W, a.ksplit = 1, a.ws = nullptr;
@@ -1534,6 +1695,62 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
   hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, st, (const double*)part, sums, nchunks,
                      (double)P * (C / 32));
   hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, (const float*)sums, gamma, beta,
+                     scale, shift, ss_stride, dx, P, C, act, accumulate, nchunks, kGnChunk);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- pieces of the GroupNorm passes for the convolutions' group-sum epilogue (fh_gn_epilogue) -------------------------
+// the block partials of an epilogue -> (mean, rstd) [mode 0] or the two backward sums [mode 1], [N][32][2] float
+int fh_groupnorm_finalize(const double* partial, float* out, int N, int chunks, double count, int mode, void* stream) {
+  if (!partial || !out || N < 1 || chunks < 1 || count <= 0 || mode < 0 || mode > 1) return FH_EINVAL;
+  if (mode == 0)
+    hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, count);
+  else
+    hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, count);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// per-(image, channel) constants of a GroupNorm backward for the mode-1 epilogue: [N][5][C] = A, Bc (t = A x + Bc, as
+// k_gn_stream), mean, rstd, gamma (1 + scale)
+__global__ __launch_bounds__(256) void k_gn_bwd_table(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int ss_stride,
+                                                      float* __restrict__ table, int C) {
+  const int n = blockIdx.x, cg = C / 32;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int64_t si = ((int64_t)n * 32 + c / cg) * 2;
+    const float mean = stats[si], rstd = stats[si + 1];
+    const float sc = scale != nullptr ? 1.f + scale[(int64_t)n * ss_stride + c] : 1.f;
+    const float sh = shift != nullptr ? shift[(int64_t)n * ss_stride + c] : 0.f;
+    const float rg = rstd * gamma[c];
+    float* t = table + (int64_t)n * 5 * C + c;
+    t[0] = rg * sc;
+    t[C] = (beta[c] - mean * rg) * sc + sh;
+    t[2 * C] = mean;
+    t[3 * C] = rstd;
+    t[4 * C] = sc * gamma[c];
+  }
+}
+
+int fh_groupnorm_bwd_table(const float* stats, const float* gamma, const float* beta, const float* scale, const float* shift,
+                           int ss_stride, float* table, int N, int C, void* stream) {
+  if (!stats || !gamma || !beta || !table || N < 1 || C % 32 != 0) return FH_EINVAL;
+  hipLaunchKernelGGL(k_gn_bwd_table, dim3(N), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale, shift, ss_stride,
+                     table, C);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// the streaming pass of fh_groupnorm_bwd alone, with the two sums given (from fh_groupnorm_finalize mode 1)
+int fh_groupnorm_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
+                           const float* beta, const float* scale, const float* shift, int ss_stride, float* dx, int N, int P,
+                           int C, int act, int accumulate, void* stream) {
+  if (!x || !dy || !stats || !sums || !gamma || !beta || !dx || C % 32 != 0) return FH_EINVAL;
+  const int kGnChunk = gn_chunk(N, P);
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, (hipStream_t)stream, x, dy, stats, sums, gamma, beta,
                      scale, shift, ss_stride, dx, P, C, act, accumulate, nchunks, kGnChunk);
   FH_LAUNCH_CHECK();
   return 0;

@@ -19,6 +19,8 @@ import threading
 import torch
 import torch.nn.functional as F
 
+import ctypes as C
+
 from . import _lib
 
 _K = 32  # K granularity of fh_conv2d_nhwc
@@ -134,10 +136,14 @@ class HipOps:
         ks = self.lib.fh_conv2d_splitk(N, H, W, Ci, c.co, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         if c.wx_f is not None and _use_x6(N, H, W, c.co):
-            _lib.check(self.lib.fh_conv2d_x6_nhwc(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
-                                                  None if res is None else res.data_ptr(), out.data_ptr(),
-                                                  None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh,
-                                                  c.kw, pad, 1, _lib.stream()), "fh_conv2d_x6_nhwc")
+            # group-sum epilogue: the statistics of a GroupNorm applied to this output come out of the convolution itself
+            epi, keep = self._epilogue(ks, N, H, W, Ci, c.co, c.kh, c.kw, pad, 0)
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
+                                                     None if res is None else res.data_ptr(), out.data_ptr(),
+                                                     None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh,
+                                                     c.kw, pad, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc")
+            if keep is not None:
+                out._fh_gn = keep
             return out
         _lib.check(self.lib.fh_conv2d_nhwc(x.data_ptr(), c.wf.data_ptr(), b.data_ptr(),
                                            None if res is None else res.data_ptr(), out.data_ptr(),
@@ -145,7 +151,10 @@ class HipOps:
                                            c.kh, c.kw, pad, 1, _lib.stream()), "fh_conv2d_nhwc")
         return out
 
-    def _dgrad(self, name, g, res=None):
+    def _dgrad(self, name, g, res=None, gn=None):
+        """Input gradient of convolution `name`.  `gn` = (norm name, x, stats, act, scale, shift) when the result is the
+        dL/dy of that GroupNorm: where the launch supports it the two sums of its backward come out of the convolution's
+        epilogue (returned as `out._fh_gn_sums` for `_gn_bwd`)."""
         c = self.conv[name]
         N, H, W, Co = g.shape
         if Co != c.co_p:  # only the 6-channel output conv: pad the cotangent to the K granularity
@@ -165,10 +174,19 @@ class HipOps:
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None
         if c.wx_d is not None and _use_x6(N, H, W, c.ci):
-            _lib.check(self.lib.fh_conv2d_x6_nhwc(g.data_ptr(), c.wx_d.data_ptr(), None,
-                                                  None if res is None else res.data_ptr(), out.data_ptr(),
-                                                  None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p, c.ci, c.kh,
-                                                  c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_x6_nhwc(dgrad)")
+            epi, keep = (None, None)
+            if gn is not None and gn[1].shape == out.shape:
+                epi, keep = self._epilogue(ks, N, H, W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1, gn)
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(g.data_ptr(), c.wx_d.data_ptr(), None,
+                                                     None if res is None else res.data_ptr(), out.data_ptr(),
+                                                     None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p, c.ci, c.kh,
+                                                     c.kw, c.kh // 2, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc(dgrad)")
+            if keep is not None:
+                partial, chunks = keep[0], keep[1]
+                sums = torch.empty(N, 32, 2, dtype=torch.float32, device=g.device)
+                _lib.check(self.lib.fh_groupnorm_finalize(partial.data_ptr(), sums.data_ptr(), N, chunks,
+                                                          float(H * W * (c.ci // 32)), 1, _lib.stream()), "gn_finalize(1)")
+                out._fh_gn_sums = sums
             return out
         _lib.check(self.lib.fh_conv2d_nhwc(g.data_ptr(), c.wd.data_ptr(), None,
                                            None if res is None else res.data_ptr(), out.data_ptr(),
@@ -176,7 +194,42 @@ class HipOps:
                                            c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_nhwc(dgrad)")
         return out
 
+    def _epilogue(self, ks, N, H, W, Ci, Co, kh, kw, pad, mode, gn=None):
+        """fh_gn_epilogue for the split-bf16 convolution launch of this layer, or (None, None) where the launch has none
+        (split-K, thin output, ...).  mode 0: statistics of the output; mode 1: backward sums of the GroupNorm `gn`."""
+        if os.environ.get("FH_GN_EPILOGUE", "1") == "0" or Co % 32 != 0:
+            return None, None
+        chunks = self.lib.fh_conv2d_x6_gn_chunks(ks, N, H, W, Ci, Co, kh, kw, pad, 1)
+        if chunks <= 0:
+            return None, None
+        dev = self.P[next(iter(self.P))].device
+        partial = torch.empty(N * chunks * 64, dtype=torch.float64, device=dev)
+        e = _lib.FhGnEpilogue()
+        e.partial, e.mode, e.act = partial.data_ptr(), mode, 0
+        keep = [partial, chunks]
+        if mode == 1:
+            gn_name, x, stats, act, scale, shift = gn
+            table = torch.empty(N, 5, Co, dtype=torch.float32, device=dev)
+            ss = 0 if scale is None else scale.stride(0)
+            _lib.check(self.lib.fh_groupnorm_bwd_table(
+                stats.data_ptr(), self.P[gn_name + ".weight"].data_ptr(), self.P[gn_name + ".bias"].data_ptr(),
+                None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss,
+                table.data_ptr(), N, Co, _lib.stream()), "gn_bwd_table")
+            e.x, e.tab, e.act = x.data_ptr(), table.data_ptr(), int(act)
+            keep.append(table)
+        return C.byref(e), keep
+
     def _gn_stats(self, x):
+        N, H, W, C_ = x.shape
+        pre = getattr(x, "_fh_gn", None)
+        if pre is not None:  # block partials left by the producing convolution's epilogue
+            stats = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
+            _lib.check(self.lib.fh_groupnorm_finalize(pre[0].data_ptr(), stats.data_ptr(), N, pre[1],
+                                                      float(H * W * (C_ // 32)), 0, _lib.stream()), "gn_finalize(0)")
+            return stats
+        return self._gn_stats_pass(x)
+
+    def _gn_stats_pass(self, x):
         N, H, W, C = x.shape
         stats = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
         scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
@@ -214,15 +267,28 @@ class HipOps:
                 None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss,
                 table.data_ptr(), N, Ci, _lib.stream()), "gn_table")
             out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
-            _lib.check(self.lib.fh_conv2d_x6_norm_nhwc(x.data_ptr(), table.data_ptr(), int(act), c.wx_f.data_ptr(),
-                                                       c.b.data_ptr(), None if res is None else res.data_ptr(),
-                                                       out.data_ptr(), N, H, W, Ci, c.co, _lib.stream()),
+            epi, keep = self._epilogue(1, N, H, W, Ci, c.co, 3, 3, 1, 0)
+            _lib.check(self.lib.fh_conv2d_x6_norm_nhwc_gn(x.data_ptr(), table.data_ptr(), int(act), c.wx_f.data_ptr(),
+                                                          c.b.data_ptr(), None if res is None else res.data_ptr(),
+                                                          out.data_ptr(), N, H, W, Ci, c.co, epi, _lib.stream()),
                        "fh_conv2d_x6_norm_nhwc")
+            if keep is not None:
+                out._fh_gn = keep
             return out, stats
         return self._conv(conv_name, self._gn_apply(gn_name, x, stats, act, scale, shift), res=res), stats
 
     def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None):
         N, H, W, C = x.shape
+        pre = getattr(dy, "_fh_gn_sums", None)
+        if pre is not None:  # the two sums came out of the producing input-gradient convolution: streaming pass only
+            dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
+            ss = 0 if scale is None else scale.stride(0)
+            _lib.check(self.lib.fh_groupnorm_bwd_apply(
+                x.data_ptr(), dy.data_ptr(), stats.data_ptr(), pre.data_ptr(), self.P[name + ".weight"].data_ptr(),
+                self.P[name + ".bias"].data_ptr(), None if scale is None else scale.data_ptr(),
+                None if shift is None else shift.data_ptr(), ss, dx.data_ptr(), N, H * W, C, int(act),
+                int(accumulate_into is not None), _lib.stream()), "gn_bwd_apply")
+            return dx
         sums = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
         scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
         dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
@@ -297,9 +363,10 @@ class HipOps:
 
     def _res_bwd(self, rec, g):
         _, op, p, x, st0, h1, st1, scale, shift = rec
-        g_h2 = self._dgrad(p + ".out_layers.3", g)
+        g_h2 = self._dgrad(p + ".out_layers.3", g, gn=(p + ".out_layers.0", h1, st1, 1, scale, shift))
         g_h1 = self._gn_bwd(p + ".out_layers.0", h1, st1, g_h2, 1, scale, shift)
-        g_h0 = self._dgrad(p + ".in_layers.2", g_h1)
+        # (with a resampling between the norm and the convolution the gradient is not yet the norm's dL/dy)
+        g_h0 = self._dgrad(p + ".in_layers.2", g_h1, gn=(p + ".in_layers.0", x, st0, 1, None, None) if op == "res" else None)
         g_xs = self._dgrad(p + ".skip_connection", g) if (p + ".skip_connection") in self.conv else g
         if op == "res_down":
             g_h0, g_xs = self._resample(g_h0, 1), self._resample(g_xs, 1)
@@ -357,7 +424,7 @@ class HipOps:
                     alpha)
         self._bgemm(dP.data_ptr(), base + qo * fs, dbase + ko * fs, T, ch, T, T, 3 * C, 3 * C, 1, 1, B_, heads, sS, s3, s3,
                     alpha)
-        g_hn = self._dgrad(p + ".qkv", dqkv)
+        g_hn = self._dgrad(p + ".qkv", dqkv, gn=(p + ".norm", x, st, 0, None, None))
         return self._gn_bwd(p + ".norm", x, st, g_hn, 0, accumulate_into=g)
 
     # ---------------------------------------------------------------- whole network

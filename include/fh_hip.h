@@ -306,6 +306,36 @@ int fh_conv2d_x6_norm_supported(int N, int H, int W, int Cin, int Cout);
 int fh_conv2d_x6_norm_nhwc(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
                            const float* res, float* out, int N, int H, int W, int Cin, int Cout, void* stream);
 
+/* Group-sum epilogue of the split-bf16 convolutions (fh_conv2d_x6_nhwc_gn / fh_conv2d_x6_norm_nhwc_gn): while a workgroup still
+ * holds its output tile in registers it also forms the per-(image, GroupNorm group) sums that the NEXT GroupNorm pass over that
+ * tensor would have to read it again for, and writes them as block partials [N][chunks][32][2] (double; chunks from
+ * fh_conv2d_x6_gn_chunks, 0 = this layer's launch has no epilogue: split-K, thin outputs, tiles across two images):
+ *   mode 0 - (sum v, sum v^2): the statistics of GroupNorm32 applied to the output (openai_nn.py:17-19; the out_layers /
+ *            next block's in_layers norm of a ResBlock, openai_unet.py:236-256) -> fh_groupnorm_finalize(mode 0) = (mean, rstd);
+ *   mode 1 - input-gradient convolutions: the output is dL/dy of a GroupNorm(+scale-shift)(+SiLU) whose forward input is `x`;
+ *            (sum g, sum g xhat) with g = dy act'(t) gamma (1 + scale), the two reductions of its backward
+ *            -> fh_groupnorm_finalize(mode 1), then fh_groupnorm_bwd_apply (the streaming pass alone).
+ * Fixed summation order: the results are deterministic. */
+typedef struct fh_gn_epilogue {
+  double* partial;     /* [N * chunks][64]; null = no epilogue */
+  const float* x;      /* mode 1: forward input of the GroupNorm, [N][Ho][Wo][Cout] */
+  const float* tab;    /* mode 1: [N][5][Cout] from fh_groupnorm_bwd_table */
+  int32_t mode, act;   /* act (mode 1): 1 = SiLU after the affine */
+} fh_gn_epilogue;
+int fh_conv2d_x6_gn_chunks(int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride);
+int fh_conv2d_x6_nhwc_gn(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
+                         int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride,
+                         const fh_gn_epilogue* epi, void* stream);
+int fh_conv2d_x6_norm_nhwc_gn(const float* in, const float* ab_table, int act, const void* wx, const float* bias,
+                              const float* res, float* out, int N, int H, int W, int Cin, int Cout, const fh_gn_epilogue* epi,
+                              void* stream);
+int fh_groupnorm_finalize(const double* partial, float* out, int N, int chunks, double count, int mode, void* stream);
+int fh_groupnorm_bwd_table(const float* stats, const float* gamma, const float* beta, const float* scale, const float* shift,
+                           int ss_stride, float* table, int N, int C, void* stream);
+int fh_groupnorm_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
+                           const float* beta, const float* scale, const float* shift, int ss_stride, float* dx, int N, int P,
+                           int C, int act, int accumulate, void* stream);
+
 /* 3x3 / stride 1 / pad 1 convolution with a thin output, Cout <= 8 (the 128 -> 6 output convolution and the
  * 128 -> 3 input gradient of the first one): direct form, w [Cout][9][Cin] as for fh_conv2d_nhwc, Cin % 32 == 0. */
 int fh_conv3x3_thin_nhwc(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin,

@@ -480,3 +480,102 @@ def test_reduced_precision_mode_vs_reference_fp16_golden(dev, gold):
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "reduced_precision_report.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(rep, open(path, "w"), indent=1)
+
+
+# ---------------------------------------------------------------- group-sum epilogue of the split-bf16 convolutions
+GN_EPI_SHAPES = [(8, 64, 64, 128, 128, 3), (2, 128, 128, 64, 384, 3), (8, 32, 32, 256, 256, 3), (1, 256, 256, 32, 128, 3),
+                 (8, 64, 64, 128, 256, 1), (2, 64, 64, 96, 160, 3)]
+
+
+@pytest.mark.parametrize("shape", GN_EPI_SHAPES)
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv_group_sum_epilogue(dev, shape, mode):
+    """fh_conv2d_x6_nhwc_gn: the block partials a convolution leaves for the GroupNorm that consumes its output.
+    mode 0 - (mean, rstd) from fh_groupnorm_finalize against fh_groupnorm_stats on the written output; mode 1 - the two
+    backward sums against those fh_groupnorm_bwd forms from (x, dy = the output) - both to 2e-6 (fp32 statistics of the same
+    numbers, different summation order), over the 256- / 128- / 64-row tile variants, a 1 x 1 convolution and channel
+    counts whose groups straddle the 128-column tiles (Cout = 384: 12 channels per group; 160: 5).  Output unchanged."""
+    from free_hunch_amd.unet_hip import _split3
+    L, lib = _lib()
+    N, H, W, Ci, Co, k = shape
+    g = torch.Generator().manual_seed(sum(shape) + 31 + mode)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dev)
+    w = (torch.randn(Co, k * k, Ci, generator=g) / math.sqrt(Ci * k * k)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    res = torch.randn(N, H, W, Co, generator=g).to(dev)
+    wx = _split3(w.contiguous())
+    pad, P = k // 2, H * W
+    chunks = lib.fh_conv2d_x6_gn_chunks(1, N, H, W, Ci, Co, k, k, pad, 1)
+    assert chunks > 0, "these shapes take the epilogue-capable launches"
+    plain = torch.empty(N, H, W, Co, device=dev)
+    L.check(lib.fh_conv2d_x6_nhwc(x.data_ptr(), wx.data_ptr(), b.data_ptr(), res.data_ptr(), plain.data_ptr(), None, 1, N, H,
+                                  W, Ci, Co, k, k, pad, 1, L.stream()), "x6")
+    partial = torch.full((N * chunks * 64,), float("nan"), dtype=torch.float64, device=dev)
+    e = L.FhGnEpilogue()
+    e.partial, e.mode, e.act = partial.data_ptr(), mode, 1
+    keep = []
+    gamma, beta = (1 + 0.1 * torch.randn(Co, generator=g)).to(dev), (0.1 * torch.randn(Co, generator=g)).to(dev)
+    scale, shift = (0.2 * torch.randn(N, Co, generator=g)).to(dev), (0.2 * torch.randn(N, Co, generator=g)).to(dev)
+    if mode == 1:
+        xin = torch.randn(N, H, W, Co, generator=g).to(dev)  # forward input of the GroupNorm whose dL/dy is the conv output
+        stats = torch.empty(N, 32, 2, device=dev)
+        scr = torch.empty(lib.fh_groupnorm_scratch_doubles(N, P), dtype=torch.float64, device=dev)
+        L.check(lib.fh_groupnorm_stats(xin.data_ptr(), stats.data_ptr(), scr.data_ptr(), N, P, Co, L.stream()), "stats")
+        table = torch.empty(N, 5, Co, device=dev)
+        L.check(lib.fh_groupnorm_bwd_table(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(),
+                                           shift.data_ptr(), Co, table.data_ptr(), N, Co, L.stream()), "table")
+        e.x, e.tab = xin.data_ptr(), table.data_ptr()
+        keep += [xin, stats, table]
+    out = torch.empty(N, H, W, Co, device=dev)
+    import ctypes as C
+    L.check(lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), wx.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, 1, N, H, W,
+                                     Ci, Co, k, k, pad, 1, C.byref(e), L.stream()), "x6 gn")
+    assert torch.equal(out, plain)
+    got = torch.empty(N, 32, 2, device=dev)
+    L.check(lib.fh_groupnorm_finalize(partial.data_ptr(), got.data_ptr(), N, chunks, float(P * (Co // 32)), mode, L.stream()), "fin")
+    scr = torch.empty(lib.fh_groupnorm_scratch_doubles(N, P), dtype=torch.float64, device=dev)
+    if mode == 0:
+        want = torch.empty(N, 32, 2, device=dev)
+        L.check(lib.fh_groupnorm_stats(out.data_ptr(), want.data_ptr(), scr.data_ptr(), N, P, Co, L.stream()), "stats")
+    else:
+        want, dx = torch.empty(N, 32, 2, device=dev), torch.empty_like(out)
+        L.check(lib.fh_groupnorm_bwd(xin.data_ptr(), out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                     scale.data_ptr(), shift.data_ptr(), Co, want.data_ptr(), scr.data_ptr(), dx.data_ptr(), N, P,
+                                     Co, 1, 0, L.stream()), "gn_bwd")
+        dx2 = torch.empty_like(out)
+        L.check(lib.fh_groupnorm_bwd_apply(xin.data_ptr(), out.data_ptr(), stats.data_ptr(), got.data_ptr(), gamma.data_ptr(),
+                                           beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), Co, dx2.data_ptr(), N, P, Co, 1, 0,
+                                           L.stream()), "gn_bwd_apply")
+        assert rel(dx2, dx) < 1e-5
+    assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())), (got - want).abs().max()
+
+
+def test_conv_group_sum_epilogue_fused_norm_input(dev):
+    """The same epilogue on the fused GroupNorm-input convolution (fh_conv2d_x6_norm_nhwc_gn), 256-row tiles."""
+    from free_hunch_amd.unet_hip import _split3
+    import ctypes as C
+    L, lib = _lib()
+    N, H, W, Ci, Co = 2, 256, 256, 64, 128
+    g = torch.Generator().manual_seed(404)
+    x = torch.randn(N, H, W, Ci, generator=g).to(dev)
+    w = (torch.randn(Co, 9, Ci, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    wx = _split3(w.contiguous())
+    assert lib.fh_conv2d_x6_norm_supported(N, H, W, Ci, Co)
+    table = torch.cat([1 + 0.1 * torch.randn(N, 1, Ci, generator=g), 0.1 * torch.randn(N, 1, Ci, generator=g)], 1).to(dev).contiguous()
+    chunks = lib.fh_conv2d_x6_gn_chunks(1, N, H, W, Ci, Co, 3, 3, 1, 1)
+    assert chunks == (H * W // 256)
+    partial = torch.full((N * chunks * 64,), float("nan"), dtype=torch.float64, device=dev)
+    e = L.FhGnEpilogue()
+    e.partial, e.mode, e.act = partial.data_ptr(), 0, 0
+    out, plain = torch.empty(N, H, W, Co, device=dev), torch.empty(N, H, W, Co, device=dev)
+    L.check(lib.fh_conv2d_x6_norm_nhwc(x.data_ptr(), table.data_ptr(), 1, wx.data_ptr(), b.data_ptr(), None, plain.data_ptr(), N,
+                                       H, W, Ci, Co, L.stream()), "norm")
+    L.check(lib.fh_conv2d_x6_norm_nhwc_gn(x.data_ptr(), table.data_ptr(), 1, wx.data_ptr(), b.data_ptr(), None, out.data_ptr(), N,
+                                          H, W, Ci, Co, C.byref(e), L.stream()), "norm gn")
+    assert torch.equal(out, plain)
+    got, want = torch.empty(N, 32, 2, device=dev), torch.empty(N, 32, 2, device=dev)
+    L.check(lib.fh_groupnorm_finalize(partial.data_ptr(), got.data_ptr(), N, chunks, float(H * W * (Co // 32)), 0, L.stream()), "fin")
+    scr = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
+    L.check(lib.fh_groupnorm_stats(out.data_ptr(), want.data_ptr(), scr.data_ptr(), N, H * W, Co, L.stream()), "stats")
+    assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))

@@ -79,17 +79,18 @@ def test_batched8_256_equals_per_image_bitwise_denoiser(dev, fold, monkeypatch):
 
 
 def test_batched8_256_equals_per_image_hip_unet(dev):
-    """The same launch shape with the HIP UNet (256 x 256, ImageNet-256 block structure at 32 channels, damped output layer:
-    tests/golden/inputs.py) and max_rtol = 1e-9, i.e. converged solves: the UNet sums over a different tile partition at
-    batch 8 than at batch 1 (1e-6 relative), which an un-converged CG would amplify to O(1) (see above) but a converged
-    one does not.  What remains is the trajectory's own gain on that 1e-6: measured 1.5e-4 .. 1.1e-3 over the eight images
-    with the output layer damped by 0.05 (the recorded fixtures' value), proportional to the damping; 0.01 here.
-    Identical k and branch lists, iteration counts within 2 %, outputs within 1e-3 (north-star tolerance)."""
+    """The same launch shape with the HIP UNet in the loop (256 x 256, ImageNet-256 block structure at 32 channels, output
+    layer damped by 0.05: the denoiser of the recorded `*_damped` fixtures) on the inpainting operator with max_rtol = 1e-6,
+    i.e. the configuration of ip256_heun12_tight_damped, which reproduces the reference's recording to 1.4e-4.  The UNet
+    sums over a different tile partition at batch 8 than at batch 1 (1e-6 relative); an un-converged CG would amplify that to
+    O(1) (see above), a converged one leaves the trajectory's own gain on it.  (Measured with gaussian_blur instead: 1.5e-4 ..
+    1.1e-3 over the eight images at max_rtol = 1e-9 - the blur systems amplify ~10x more than the mask; that operator is
+    covered bitwise by the test above.)  Identical k and branch lists, iteration counts within 2 %, outputs within 1e-3."""
     from free_hunch_amd.sampler import conditional_sampler, conditional_sampler_batched
     B, S = 8, 256
-    net = nets.damped_hip_net(inputs.SMALL_C, 13, dev, damp=0.01)
-    kw = _base_kwargs(DATA, {"max_rtol": 1e-9})
-    ops, ys, noise = _batch_inputs(B, S, dev)
+    net = nets.damped_hip_net(inputs.SMALL_C, 13, dev)
+    kw = _base_kwargs(DATA, {"max_rtol": 1e-6})
+    ops, ys, noise = _batch_inputs(B, S, dev, "inpainting")
     run = dict(num_steps=6, sigma_min=0.002, sigma_max=80, rho=7, solver="heun")
     xb = conditional_sampler_batched(net, noise, ys, ops, **run, **kw)
     tb = [m.trace for m in conditional_sampler_batched.last_mechanisms]
