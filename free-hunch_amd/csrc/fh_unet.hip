@@ -214,25 +214,25 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v))
 // shuffle, every wave leaves its 32 x NI channel sums in LDS and 64 threads add them per (group, which) in a FIXED order
 // (deterministic) and write the block's partial: the statistics pass of the consuming GroupNorm (mode 0: sum v, sum v^2) or the
 // two sums of its backward (mode 1: sum g, sum g xhat with g = dy act'(t) gamma (1 + scale)) never read the tensor again.
-struct GnAcc {
-  double s0, s1;
+struct GnAcc {  // per lane: <= 32 values of one channel, summed in fp32 (then widened for the cross-lane / cross-tile sums)
+  float s0, s1;
 };
 __device__ __forceinline__ void gn_accum(const ConvArgsX& a, GnAcc& g, float v, int64_t row, int co, const float (&tb)[5]) {
   if (a.gn_mode == 0) {
     g.s0 += v;
-    g.s1 += (double)v * v;
+    g.s1 = fmaf(v, v, g.s1);
   } else {
     const float x = a.gn_x[row * a.Cout + co];
     const float t = fmaf(x, tb[0], tb[1]);
     const float xh = (x - tb[2]) * tb[3];
     float gg = v;
     if (a.gn_act) {
-      const float sg = 1.f / (1.f + __expf(-t));
-      gg *= sg * (1.f + t * (1.f - sg));
+      const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-t));  // (1 ulp reciprocal: these are sums of ~1e5 terms)
+      gg *= sg * fmaf(t, 1.f - sg, 1.f);
     }
     gg *= tb[4];
     g.s0 += gg;
-    g.s1 += (double)gg * xh;
+    g.s1 = fmaf(gg, xh, g.s1);
   }
 }
 template <int NI, int WM, int WN, int BN>
@@ -240,8 +240,8 @@ __device__ __forceinline__ void gn_reduce(const ConvArgsX& a, const GnAcc (&g)[N
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const double s0 = g[j].s0 + __shfl_xor(g[j].s0, 32, 64);
-    const double s1 = g[j].s1 + __shfl_xor(g[j].s1, 32, 64);
+    const double s0 = (double)g[j].s0 + (double)__shfl_xor(g[j].s0, 32, 64);
+    const double s1 = (double)g[j].s1 + (double)__shfl_xor(g[j].s1, 32, 64);
     if (lane < 32) {
       gred[((wave * 32 + lr) * NI + j) * 2 + 0] = s0;
       gred[((wave * 32 + lr) * NI + j) * 2 + 1] = s1;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
   GnAcc gsum[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    gsum[j].s0 = gsum[j].s1 = 0.0;
+    gsum[j].s0 = gsum[j].s1 = 0.f;
     const int co = n0 + wn + j * 32 + lr;
     if (co >= a.Cout) continue;
     const float bv = (a.bias != nullptr && a.ksplit == 1) ? a.bias[co] : 0.f;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   GnAcc gsum[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    gsum[j].s0 = gsum[j].s1 = 0.0;
+    gsum[j].s0 = gsum[j].s1 = 0.f;
     const int co = n0 + wn + j * 32 + lr;
     if (co >= a.Cout) continue;
     const float bv = a.bias != nullptr ? a.bias[co] : 0.f;
