@@ -396,6 +396,28 @@ def _free_port():
         return s_.getsockname()[1]
 
 
+def rank_cpu_threads(world):
+    """CPU threads per rank: physical cores / world (logical CPUs / 2 where /proc/cpuinfo does not tell), capped at 32."""
+    phys = None
+    try:
+        cores = set()
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    phys = phys or max(1, (os.cpu_count() or 2) // 2)
+    return max(1, min(32, phys // max(1, world)))
+
+
 def launch_ranks(n, argv, script=None, env=None, timeout=None):
     """Start one child process per GPU (the launch model of the reference's torch_utils/distributed.py:19-45: env://
     rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for all of them.  Rank 0's child
@@ -404,8 +426,15 @@ def launch_ranks(n, argv, script=None, env=None, timeout=None):
     import subprocess
     script = os.path.abspath(__file__) if script is None else script
     base = dict(os.environ if env is None else env)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool support only dmabuf IPC; without it RCCL's (and torch's) cross-process
+    # buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  Kept if the caller already set it.
     base.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base.get("MASTER_PORT") or _free_port()),
                 HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # one rank per GPU shares the host: cap each rank's CPU thread pools at its share of the cores (the host side of a rank
+    # is launch-bound Python + a few small torch-CPU ops; 256 OpenMP threads per rank x 8 ranks only fight each other)
+    share = str(max(1, rank_cpu_threads(n)))
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        base.setdefault(var, share)
     procs = []
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))

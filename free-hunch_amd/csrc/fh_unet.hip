@@ -482,16 +482,27 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // pulls 1.33 B per pixel (fp32, every third tap) but 6 B per output channel (three bf16 planes, every tap): arithmetic
 // intensity 2 BM BN / (1.33 BM + 6 BN) = 35 flop/B at 128 x 128 (-> ~190 TFLOP/s fp32-equivalent, as measured) and 59 at
 // 256 x 128, past the 50 flop/B where the MFMAs at the held clock become the limit.
-template <int SEGW, bool NORM = false, int BM = 128, int NP = 3>  // SEGW: pixels per row segment of the tile (W, capped at BM)
+// GL: the weight tile arrives by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write pass) into one of TWO
+// buffers, issued a tap ahead and retired by the single barrier of the tap (one barrier per tap instead of two).  The DMA
+// image is lane-linear (64-byte rows, no padding), so the bank spread of the 16-byte fragment reads comes from a swizzle of
+// the 16-byte chunk index with bits 2..3 of the row, applied on the per-lane SOURCE address and on the read.
+template <int SEGW, bool NORM = false, int BM = 128, int NP = 3, bool GL = false>  // SEGW: pixels per row segment of the tile (W, capped at BM)
 __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   constexpr int MI = 2, NI = 1, WN = 4, T = 4 * BM;
   constexpr int NSEG = BM / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
   constexpr int BN = 128, AR = NSEG * SP;
   constexpr int IA = (AR * 8 + T - 1) / T;  // float4 items per thread for the activation tile (1040 items)
   constexpr int IB = (NP * BN * 4 + T - 1) / T;  // 16-byte items per thread for the weight tile (1536 items at NP = 3)
-  __shared__ __align__(16) __bf16 As[NP][AR][kXLd];
-  constexpr int NB = 1;  // (a second weight buffer in the 256-pixel variant, one barrier per tap, was measured: no gain)
-  __shared__ __align__(16) __bf16 Bs[NB][NP][BN][kXLd];
+  constexpr int NB = GL ? 2 : 1;          // (a second REGISTER-staged weight buffer was measured: no gain)
+  constexpr int BLD = GL ? kBK : kXLd;    // weight-row stride in LDS
+  // ONE __shared__ object for everything: beside an LDS-DMA staging array a second __shared__ object makes hipcc wait
+  // vmcnt(0) before the first ds_read of every step, i.e. serialises the DMA with the MFMAs
+  constexpr int kAsBytes = NP * AR * kXLd * 2, kBsBytes = NB * NP * BN * BLD * 2;
+  constexpr int kGredBytes = (BM / 64) * WN * 32 * NI * 2 * 8;
+  __shared__ __align__(16) unsigned char smem[kAsBytes + kBsBytes + kGredBytes];
+  __bf16 (*As)[AR][kXLd] = reinterpret_cast<__bf16 (*)[AR][kXLd]>(smem);
+  __bf16 (*Bs)[NP][BN][BLD] = reinterpret_cast<__bf16 (*)[NP][BN][BLD]>(smem + kAsBytes);
+  double* gred = reinterpret_cast<double*>(smem + kAsBytes + kBsBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = (wave / WN) * (MI * 32), wn = (wave % WN) * (NI * 32);
   const int lr = lane & 31, lh = lane >> 5;
@@ -560,6 +571,22 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       rb_reg[e] = b_ok[e] ? *reinterpret_cast<const bf16x8_t*>(src) : z;
     }
   };
+  // LDS-DMA form: piece p = (plane p / 8, rows 16 (p % 8) .. + 15) is one wave-instruction of 64 x 16 bytes
+  auto issue_b = [&](int cc, int tap, int buf) {
+    const __bf16* wbase = a.wx + ((int64_t)tap * cpt + cc) * a.Cout * kBK;
+    for (int p = wave; p < NP * 8; p += T / 64) {
+      const int plane = p >> 3, row = (p & 7) * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      int grow = n0 + row;
+      grow = grow < a.Cout ? grow : a.Cout - 1;  // columns beyond Cout only feed accumulators that are never stored
+      const __bf16* src = wbase + plane * wplane + (int64_t)grow * kBK + ch * 8;
+#if defined(__HIP_DEVICE_COMPILE__)  // (the builtin exists in the device pass only; the host pass needs just the stub)
+      __builtin_amdgcn_global_load_lds(src, &Bs[buf][plane][(p & 7) * 16][0], 16, 0, 0);
+#else
+      (void)src;
+#endif
+    }
+  };
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
   auto store_a = [&]() {
 #pragma unroll
@@ -610,7 +637,11 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][arow[i] + kx][ko]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[bbuf][p][wn + j * 32 + lr][ko]);
+        for (int j = 0; j < NI; ++j) {
+          const int brow = wn + j * 32 + lr;
+          const int bko = GL ? (((ko >> 3) ^ ((brow >> 2) & 3)) << 3) : ko;
+          bfr[p][j] = *reinterpret_cast<const bf16x8_t*>(&Bs[bbuf][p][brow][bko]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -632,6 +663,27 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
     }
   };
   // chunk c = (cc * 3 + ky) * 3 + kx
+  if (GL) {
+    load_a(0, 0);
+    issue_b(0, 0, 0);
+    store_a();
+    __syncthreads();  // (the barrier's fence also retires the DMA)
+    for (int c = 0; c < nchunks; ++c) {
+      const int kx = c % 3, nx = c + 1;
+      const bool more = nx < nchunks, new_row = more && (nx % 3 == 0);
+      if (more) {
+        const int ncc = nx / 9, nky = (nx / 3) % 3, nkx = nx % 3;
+        issue_b(ncc, nky * 3 + nkx, nx & 1);  // buffer nx & 1 was last read in iteration c - 1, before its barrier
+        if (new_row) load_a(ncc, nky);
+      }
+      compute(kx, c & 1);
+      __syncthreads();
+      if (new_row) {
+        store_a();
+        __syncthreads();
+      }
+    }
+  } else {
   load_a(0, 0);
   load_b(0, 0);
   store_a();
@@ -657,8 +709,8 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       }
     }
   }
+  }
   const int64_t M = (int64_t)a.N * a.Ho * a.Wo;
-  __shared__ double gred[(BM / 64) * WN * 32 * NI * 2];
   const bool gn = a.gn_partial != nullptr;
   GnAcc gsum[NI];
 #pragma unroll
@@ -1485,7 +1537,14 @@ static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, co
     static const int no_big = getenv("FH_X6_NOBIG") != nullptr;
     const bool big = r3 && !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
-    if (big && W % 256 == 0)
+    static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;  // weight tile by LDS-DMA (default; 0 = register staging, the A/B switch)
+    if (big && glds && W % 256 == 0)
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    else if (big && glds && W == 128 && H % 2 == 0)
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    else if (big && glds && W == 64 && H % 4 == 0)
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    else if (big && W % 256 == 0)
       X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
       X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), gbig, dim3(1024), 0, st, a);
@@ -1586,7 +1645,14 @@ static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, 
   static const int no_big = getenv("FH_X6_NOBIG") != nullptr;
   const bool big = !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
-  if (big && W % 256 == 0)
+  static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;
+  if (big && glds && W % 256 == 0)
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+  else if (big && glds && W == 128 && H % 2 == 0)
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+  else if (big && glds && W == 64 && H % 4 == 0)
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+  else if (big && W % 256 == 0)
     X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
     X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), gbig, dim3(1024), 0, st, a);

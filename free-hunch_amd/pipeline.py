@@ -14,30 +14,43 @@ def shard_indices(total, rank, world):
     return list(range(rank, total, world))
 
 
-def gather_images(local_u8, local_idx, total, device):
-    """One all_gather of uint8 [n_local,3,S,S] (+ int64 indices); returns the [total,3,S,S] tensor ordered by index on
-    every rank.  Ranks with fewer images pad with index -1."""
+def gather_images(local_u8, local_idx, total, device, partial_sums=None):
+    """THE exchange of a run: ONE all_gather (RCCL over xGMI on the GPUs, gloo in the CPU rehearsals) of one uint8 payload
+    per rank = [partial sums as float64 | per image: int64 global index, uint8 pixels].  Returns the [total,3,S,S] tensor
+    ordered by index on every rank - and, when `partial_sums` (a 1-D float64 tensor, e.g. the metric sums of
+    generate_conditional.py:557-569) is given, also their sum over ranks, so that no separate all_reduce is needed.
+    Ranks with fewer images pad with index -1."""
+    shape = tuple(local_u8.shape[1:])
+    nsum = 0 if partial_sums is None else int(partial_sums.numel())
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        out = torch.zeros((total,) + tuple(local_u8.shape[1:]), dtype=torch.uint8, device=local_u8.device)
+        out = torch.zeros((total,) + shape, dtype=torch.uint8, device=local_u8.device)
         out[torch.as_tensor(local_idx, dtype=torch.long, device=local_u8.device)] = local_u8
-        return out
+        return out if partial_sums is None else (out, partial_sums.clone())
     world = dist.get_world_size()
     n_max = (total + world - 1) // world
-    shape = tuple(local_u8.shape[1:])
-    buf = torch.zeros((n_max,) + shape, dtype=torch.uint8, device=device)
+    img_bytes = int(np.prod(shape))
+    rec = 8 + img_bytes                       # int64 index + pixels
+    payload = torch.zeros(8 * nsum + n_max * rec, dtype=torch.uint8, device=device)
+    if nsum:
+        payload[: 8 * nsum] = partial_sums.detach().to(device=device, dtype=torch.float64).contiguous().view(torch.uint8)
+    body = payload[8 * nsum:].view(n_max, rec)
     idx = torch.full((n_max,), -1, dtype=torch.int64, device=device)
     n = local_u8.shape[0]
-    buf[:n] = local_u8.to(device)
     idx[:n] = torch.as_tensor(local_idx, dtype=torch.int64, device=device)
-    all_buf = [torch.empty_like(buf) for _ in range(world)]
-    all_idx = [torch.empty_like(idx) for _ in range(world)]
-    dist.all_gather(all_buf, buf)
-    dist.all_gather(all_idx, idx)
+    body[:, :8] = idx.view(torch.uint8).view(n_max, 8)
+    body[:n, 8:] = local_u8.to(device).reshape(n, img_bytes)
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload)
     out = torch.zeros((total,) + shape, dtype=torch.uint8, device=device)
-    for b, i in zip(all_buf, all_idx):
+    sums = torch.zeros(nsum, dtype=torch.float64, device=device)
+    for g in gathered:
+        if nsum:
+            sums += g[: 8 * nsum].clone().view(torch.float64)
+        gb = g[8 * nsum:].view(n_max, rec)
+        i = gb[:, :8].contiguous().view(torch.int64).view(n_max)
         keep = i >= 0
-        out[i[keep]] = b[keep]
-    return out
+        out[i[keep]] = gb[keep][:, 8:].reshape((-1,) + shape)
+    return out if partial_sums is None else (out, sums)
 
 
 def metrics_u8(a, b):

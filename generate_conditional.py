@@ -112,15 +112,13 @@ def main(argv=None):
     local_cond = torch.cat(conds) if conds else torch.zeros((0, 3, S, S), dtype=torch.uint8, device=device)
     ns = len(o.seeds)
     unit_ids = [i * ns + o.seeds.index(sd) for i, sd in units]  # global position of (image, seed)
-    all_out = gather_images(local_out, unit_ids, total * ns, device)   # the single exchange of the run
-    all_cond = gather_images(local_cond, unit_ids, total * ns, device)
-    # metrics as in generate_conditional.py:539-569: per image on the device (fh_metrics_u8), partial sums reduced over ranks
+    # metrics as in generate_conditional.py:539-569: per image on the device (fh_metrics_u8); the partial sums travel in the
+    # header of the ONE all_gather that collects the images (the reference: a barrier per image + three all_reduces)
     sums = torch.zeros(3, dtype=torch.float64, device=device)
     if local_out.shape[0]:
         ps, ss = metrics_u8(local_out, local_cond)
         sums = torch.stack([ps.sum(), ss.sum(), torch.tensor(float(local_out.shape[0]), dtype=torch.float64, device=device)])
-    if world > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    all_out, sums = gather_images(local_out, unit_ids, total * ns, device, partial_sums=sums)  # the single exchange of the run
     psnr_mean, ssim_mean = float(sums[0] / sums[2]), float(sums[1] / sums[2])
     name = lambda u: f"{u // ns:06d}_{o.seeds[u % ns]:06d}.png"
     import PIL.Image
@@ -130,8 +128,8 @@ def main(argv=None):
         for u in range(total * ns):
             PIL.Image.fromarray(all_out[u].permute(1, 2, 0).cpu().numpy(), "RGB").save(
                 os.path.join(o.outdir, "images", name(u)))
-            if u % ns == 0:
-                PIL.Image.fromarray(all_cond[u].permute(1, 2, 0).cpu().numpy(), "RGB").save(
+            if u % ns == 0:  # the ground-truth images are not exchanged: rank 0 reads them from the dataset itself
+                PIL.Image.fromarray(load_image_u8(files[u // ns], S).permute(1, 2, 0).numpy(), "RGB").save(
                     os.path.join(o.outdir, "cond_images", name(u)))
         with open(os.path.join(o.outdir, "results.txt"), "w") as f:
             f.write(f"PSNR: {psnr_mean:.4f}\nSSIM: {ssim_mean:.4f}\nimages: {total * ns}\n")

@@ -27,8 +27,16 @@ def _worker(rank, world, port, total, q):
     mine = shard_indices(total, rank, world)
     local = torch.stack([torch.full((3, 4, 4), (7 * i + 1) % 256, dtype=torch.uint8) for i in mine]) if mine else \
         torch.zeros((0, 3, 4, 4), dtype=torch.uint8)
-    out = gather_images(local, mine, total, torch.device("cpu"))
-    q.put((rank, mine, out.numpy().copy()))
+    # the metric partial sums ride in the header of the same (single) all_gather
+    part = torch.tensor([float(sum(mine)), float(len(mine)), 0.25 * (rank + 1)], dtype=torch.float64)
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real_ar = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), real_ar(*a, **k))[1]
+    out, sums = gather_images(local, mine, total, torch.device("cpu"), partial_sums=part)
+    dist.all_gather, dist.all_reduce = real, real_ar
+    q.put((rank, mine, out.numpy().copy(), sums.numpy().copy(), calls))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,12 +53,43 @@ def test_shard_and_all_gather_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    seen = sorted(i for _r, mine, _o in res for i in mine)
+    seen = sorted(i for _r, mine, _o, _s, _c in res for i in mine)
     assert seen == list(range(total))
-    for _r, _mine, out in res:
+    for _r, _mine, out, sums, calls in res:
         assert out.shape == (total, 3, 4, 4)
         for i in range(total):
             assert (out[i] == (7 * i + 1) % 256).all()
+        # partial sums of both ranks, summed: image indices 0..6, image count, and the rank tags 0.25 + 0.5
+        assert sums.tolist() == [float(sum(range(total))), float(total), 0.75]
+        assert calls == [1], calls  # exactly ONE collective: no second all_gather for the indices, no all_reduce
+
+
+def test_launcher_caps_cpu_threads_per_rank(monkeypatch):
+    """bench.launch_ranks gives every rank its share of the host's cores (OMP / MKL pools) unless the caller chose."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert 1 <= bench.rank_cpu_threads(8) <= bench.rank_cpu_threads(1) <= 32
+    seen = {}
+
+    class P:
+        def __init__(self, argv, env):
+            seen.setdefault("envs", []).append(env)
+
+        def poll(self):
+            return 0
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", P)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    monkeypatch.delenv("MKL_NUM_THREADS", raising=False)
+    assert bench.launch_ranks(2, []) == 0
+    for e in seen["envs"]:
+        assert e["OMP_NUM_THREADS"] == e["MKL_NUM_THREADS"] == str(bench.rank_cpu_threads(2))
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["MASTER_ADDR"] == "127.0.0.1"
+    seen.clear()
+    monkeypatch.setenv("OMP_NUM_THREADS", "3")
+    assert bench.launch_ranks(2, []) == 0
+    assert all(e["OMP_NUM_THREADS"] == "3" for e in seen["envs"])
 
 
 def _run_launcher(extra):
