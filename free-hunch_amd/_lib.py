@@ -91,6 +91,8 @@ _SIGS = {
     "fh_groupnorm_finalize": ([c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p], C.c_int),
     "fh_groupnorm_bwd_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_groupnorm_bwd_apply": ([c_dp] * 8 + [C.c_int, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
+    "fh_groupnorm_bwd_sums": ([c_dp] * 7 + [C.c_int, c_dp, c_dp] + [C.c_int] * 4 + [C.c_void_p], C.c_int),
+    "fh_groupnorm_bwd_apply_ex": ([c_dp] * 8 + [C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
     "fh_unet_set_precision": ([C.c_int], C.c_int),
     "fh_groupnorm_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),

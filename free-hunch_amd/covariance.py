@@ -167,7 +167,11 @@ class CovarianceHessianBFGS:
         while cap < need:
             cap *= 2
         if cap > _lib_max_cols():
-            raise _lib.FhError(f"more than {_lib_max_cols()} factor columns requested")
+            hint = ""
+            if self.max_vector_count is not None and 0 < self.max_vector_count < _lib_max_cols() // 2:
+                hint = (f" (max_vector_count={self.max_vector_count} truncates the INNER matrix only: the base keeps every "
+                        f"raw pair, so a run is limited to {_lib_max_cols() // 2} space updates; the reference has no such limit)")
+            raise _lib.FhError(f"more than {_lib_max_cols()} factor columns requested" + hint)
         for fam in (self.famC, self.famH):
             fam.grow(cap)
         for rep in (self.C, self.Ci, self.H, self.Hi):
@@ -322,7 +326,11 @@ class CovarianceHessianBFGS:
         shift_c = float(np.float32(sigma_tnext ** (-2) - sigma_t ** (-2)))
         shift_h = -float(np.float32(sigma_tnext ** 2 - sigma_t ** 2))
         if max(self.famC.m, self.famH.m) <= 64 and os.environ.get("FH_COV_STEPWISE") != "1" and not self._track:
-            # one C call enqueues the whole update (same kernels, same order as the step-by-step path below)
+            # one C call enqueues the whole update: the FORWARD-shift formulation (D / (1 + sD), M (I + sGM)^-1, double-double
+            # refined; include/fh_hip.h).  The step-by-step path below (beyond 64 columns, FH_COV_STEPWISE=1, factor tracking
+            # for 0 < max_vector_count) still follows the reference's route - shift the inverse representation, Woodbury back
+            # with the 1/D-weighted Gram - whose float64 accuracy at d = 196608 with the DCT prior is that of the reference itself
+            # (1e-6 .. 1e-4 below sigma = 0.2 on real states, profiles/r02_time_shift_accuracy.md), not the fused path's 1e-8
             ctx = self.ctx
             if only_covariance:
                 _lib.check(ctx.lib.fh_cov_time_update(ctx.h, C.byref(self._state()), None, None, shift_c, shift_h, 0.0, 1,

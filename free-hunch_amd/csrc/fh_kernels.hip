@@ -197,7 +197,11 @@ template <bool INV>
 __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, const double* __restrict__ X,
                                                  double* __restrict__ C, int S, int planes,
                                                  const fh_cg_state* __restrict__ states, const double* __restrict__ add,
-                                                 double add_scale, fh_diag_tab dg) {
+                                                 double add_scale, fh_diag_tab dg, double* __restrict__ dot_part,
+                                                 int dot_stride) {
+  // dot_part != null (with add): the workgroup also leaves sum(add .* out) of every (plane, tile) it completes in
+  // dot_part[image * dot_stride + (plane % 3) * tiles + tile] - the p.Ap reduction of the CG iteration rides in the pass
+  // that produces Ap (A p = sigma_y^2 p + ..., add = p), summed later in a fixed order
   // K chunks of 64 (two per plane at S = 256): the per-chunk cost besides the 16 MFMA pairs - LDS stores, the barrier, the
   // wait for the prefetched rows - was ~65 % of a 32-wide chunk's time (measured 14.4 us per pass at BK = 32, 36 % of the f64
   // MFMA rate); halving the chunk count halves it.  Two LDS buffers, the next chunk prefetched into registers.
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
       const double* Ap = add != nullptr ? add + (int64_t)plane * S * S : nullptr;
       const double* Dp = dg.D[0] != nullptr ? dg.D[plane / 3] + (int64_t)(plane % 3) * S * S : nullptr;
       const int col = r0 + rw + li;
+      double dsum = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int jj = j0 + jw + lk + 4 * q;
@@ -304,8 +309,20 @@ __global__ __launch_bounds__(256) void k_dct_sym(const double* __restrict__ Ah, 
           v0 = acc_e[q], v1 = acc_o[q];
         }
         if (Dp != nullptr) v0 = Dp[o0] * v0, v1 = Dp[o1] * v1;  // same product as k_rep_apply2 forms for m = 0
-        Cp[o0] = Ap != nullptr ? fma(add_scale, Ap[o0], v0) : v0;
-        Cp[o1] = Ap != nullptr ? fma(add_scale, Ap[o1], v1) : v1;
+        if (Ap != nullptr) {
+          const double a0 = Ap[o0], a1 = Ap[o1];
+          v0 = fma(add_scale, a0, v0), v1 = fma(add_scale, a1, v1);
+          dsum = fma(a0, v0, fma(a1, v1, dsum));
+        }
+        Cp[o0] = v0;
+        Cp[o1] = v1;
+      }
+      if (dot_part != nullptr) {  // (uniform: every thread of the workgroup completes the plane in this iteration)
+        __shared__ double dred[4];
+        dsum = block_sum_256(dsum, dred);
+        if (tid == 0)
+          dot_part[(int64_t)(plane / 3) * dot_stride + (plane % 3) * (int)(gridDim.x * gridDim.y) + blockIdx.y * gridDim.x +
+                   blockIdx.x] = dsum;
       }
       acc_e = double4_t{0.0, 0.0, 0.0, 0.0};
       acc_o = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -324,7 +341,8 @@ static int dct2d_launch_bases(fh_context* ctx, const double* in, double* out, in
 // the two symmetric passes: tmp = (X P_w^T)^T, out = P_h X P_w^T (+ add_scale * add); sym_* = packed half bases [2][S/2][S/2]
 static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int planes, const double* sym_w,
                             const double* sym_h, int inverse, const double* add, double add_scale,
-                            const fh_cg_state* states, hipStream_t st, const fh_batch* diag = nullptr) {
+                            const fh_cg_state* states, hipStream_t st, const fh_batch* diag = nullptr,
+                            double* dot_part = nullptr, int dot_stride = 0, int* dot_nparts = nullptr) {
   const int S = ctx->S, H = S / 2;
   if (planes > ctx->planes_max || S % 128 != 0) return FH_ESIZE;
   const int gx = S / 32, gy = H / 32;
@@ -348,16 +366,18 @@ static int dct2d_launch_sym(fh_context* ctx, const double* in, double* out, int 
   memset(&dg, 0, sizeof(dg));
   if (diag != nullptr)
     for (int i = 0; i < diag->nimg && i < FH_MAX_BATCH; ++i) dg.D[i] = diag->D[i];
+  if (add == nullptr || 3 * gx * gy > 256) dot_part = nullptr;  // (the consumer sums <= 256 partials per image)
+  if (dot_nparts != nullptr) *dot_nparts = dot_part != nullptr ? 3 * gx * gy : 0;
   if (inverse) {
     hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
-                       (const double*)nullptr, 0.0, none);
+                       (const double*)nullptr, 0.0, none, (double*)nullptr, 0);
     hipLaunchKernelGGL(k_dct_sym<true>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
-                       add, add_scale, dg);
+                       add, add_scale, dg, dot_part, dot_stride);
   } else {
     hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_w, in, ctx->tmp_img, S, planes, states,
-                       (const double*)nullptr, 0.0, none);
+                       (const double*)nullptr, 0.0, none, (double*)nullptr, 0);
     hipLaunchKernelGGL(k_dct_sym<false>, grid, dim3(256), lds, st, sym_h, (const double*)ctx->tmp_img, out, S, planes, states,
-                       add, add_scale, dg);
+                       add, add_scale, dg, dot_part, dot_stride);
   }
   FH_LAUNCH_CHECK();
   return 0;
@@ -1086,6 +1106,8 @@ __global__ __launch_bounds__(256) void k_mask(fh_batch per, const double* __rest
 }
 
 constexpr int kDotBlocks = 256;
+constexpr int kCgBlocks = 192;
+constexpr int kCgScratch = 4 * kDotBlocks + 16;  // doubles of w2 per image: [pAp | b.b | r.r | - | rzbuf[2]]
 
 // partial[b] = sum over block b of a.*b ; optional second product a2.*b2 -> partial[kDotBlocks + b]   (grid z = image)
 __global__ __launch_bounds__(256) void k_dot_partial(const double* __restrict__ a, const double* __restrict__ b,
@@ -1955,8 +1977,13 @@ static int conv_launch(fh_context* ctx, const double* in, double* out, const int
 // ------------------------------------------------------------------------------------------------
 // A_mm(u) = sigma_y^2 u + A C A^T u       (conditioning_mechanisms.py:395-400, 505-511, 653-659)
 // ------------------------------------------------------------------------------------------------
+// dot_part / dot_nparts (CG only): where the operator's last pass can also reduce u . (A u) per image it writes *dot_nparts
+// block partials per image to dot_part (stride kCgScratch) - the caller then skips its own dot kernel; else *dot_nparts = 0
 static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per, const double* u, double* out,
-                      const fh_cg_state* states, hipStream_t st) {
+                      const fh_cg_state* states, hipStream_t st, double* dot_part = nullptr, int* dot_nparts = nullptr) {
+  if (dot_nparts != nullptr) *dot_nparts = 0;
+  static const bool no_dot_fuse = getenv("FH_CG_NO_DOT_FUSE") != nullptr;  // A/B switch
+  if (no_dot_fuse) dot_part = nullptr;
   const int S = ctx->S;
   const int64_t d = p->d;  // per image
   const int nimg = per.nimg;
@@ -1978,13 +2005,15 @@ static int amm_launch(fh_context* ctx, const fh_problem* p, const fh_batch& per,
         // D .* z rides in the epilogue of the forward pass - two kernels per apply instead of three
         rc = dct2d_launch_sym(ctx, u, w0, planes, p->fold_fwd_w, p->fold_fwd_h, 0, nullptr, 0.0, states, st, &per);
         if (rc) return rc;
-        return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st);
+        return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st, nullptr,
+                                dot_part, kCgScratch, dot_nparts);
       }
       rc = dct2d_launch_sym(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, 0, nullptr, 0.0, states, st);
       if (rc) return rc;
       rc = rep_apply_launch(ctx, per, p->ldm, w1, w0, d, p->m, states, st);
       if (rc) return rc;
-      return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st);
+      return dct2d_launch_sym(ctx, w0, out, planes, p->fold_inv_w, p->fold_inv_h, 1, u, p->sigma_y2, states, st, nullptr,
+                              dot_part, kCgScratch, dot_nparts);
     }
     rc = dct2d_launch_bases(ctx, u, w1, planes, p->fold_fwd_w, p->fold_fwd_h, nullptr, 0.0, states, st);
     if (rc) return rc;
@@ -2056,8 +2085,6 @@ static fh_batch batch_of(const fh_problem* p) {
 // Conjugate gradients, conditioning_utils/cg.py:232-282 (M = I, x0 = b).  Scalars stay on the device;
 // the two reductions per iteration are block partials re-summed by every workgroup of the next kernel.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCgBlocks = 192;
-constexpr int kCgScratch = 4 * kDotBlocks + 16;  // doubles of w2 per image: [pAp | b.b | r.r | - | rzbuf[2]]
 
 __device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* red) {
   double s = threadIdx.x < n ? part[threadIdx.x] : 0.0;
@@ -2305,9 +2332,25 @@ int fh_context_destroy(fh_context* c) {
   return 0;
 }
 
+// a captured CG chunk bakes in the apply kernel that `exclusive` / `fused_disabled` selected at capture time: drop the cached
+// graphs whenever that selection can change, so a graph never replays the single-sweep kernel on a context that has since
+// lost its exclusivity (or had a time-out reported)
+static void drop_graphs(fh_context* ctx) {
+  for (auto& g : ctx->graphs) {
+    if (g.exec != nullptr) {
+      (void)hipGraphExecDestroy(g.exec);
+      (void)hipGraphDestroy(g.graph);
+      g.exec = nullptr;
+      g.graph = nullptr;
+    }
+  }
+}
+
 int fh_context_set_exclusive(fh_context* ctx, int exclusive) {
   if (!ctx) return FH_EINVAL;
-  ctx->exclusive = exclusive < 0 ? 0 : (exclusive > 2 ? 2 : exclusive);
+  const int e = exclusive < 0 ? 0 : (exclusive > 2 ? 2 : exclusive);
+  if ((e >= 2) != (ctx->exclusive >= 2)) drop_graphs(ctx);  // (levels 0 and 1 select the same kernels)
+  ctx->exclusive = e;
   return 0;
 }
 
@@ -2328,6 +2371,7 @@ int fh_context_status(fh_context* ctx, void* stream) {
   // a single-sweep apply timed out waiting for its peers (another grid-synchronising kernel shared the GPU): its output
   // is invalid.  Re-arm the counters, keep this context on the two-pass kernels and report.
   ctx->fused_disabled = 1;
+  drop_graphs(ctx);
   FH_CHECK(hipMemsetAsync(ctx->sync, 0, sizeof(unsigned int) * (FH_MAX_BATCH * kSyncStride + 32), (hipStream_t)stream));
   FH_CHECK(hipStreamSynchronize((hipStream_t)stream));
   return FH_ESYNC;
@@ -2717,12 +2761,16 @@ static int cg_enqueue_chunk(fh_context* ctx, const fh_problem* p, const fh_batch
   fh_cg_state* stt = ctx->cg_state;
   const dim3 grid(kCgBlocks, 1, (unsigned)per.nimg);
   for (int i = 0; i < count; ++i) {
-    int rc = amm_launch(ctx, p, per, pk, ap, stt, st);
+    int dot_n = 0;  // > 0: the operator's last pass already left the p.Ap block partials
+    int rc = amm_launch(ctx, p, per, pk, ap, stt, st, part, &dot_n);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_dot_partial, grid, dim3(256), 0, st, (const double*)pk, (const double*)ap,
-                       (const double*)nullptr, (const double*)nullptr, part, n, kCgScratch, (const fh_cg_state*)stt);
+    if (dot_n == 0) {
+      hipLaunchKernelGGL(k_dot_partial, grid, dim3(256), 0, st, (const double*)pk, (const double*)ap,
+                         (const double*)nullptr, (const double*)nullptr, part, n, kCgScratch, (const fh_cg_state*)stt);
+      dot_n = kCgBlocks;
+    }
     hipLaunchKernelGGL(k_cg_step1, grid, dim3(256), 0, st, (const double*)pk, (const double*)ap, x, r,
-                       (const double*)part, kCgBlocks, part + 2 * kDotBlocks, (const double*)rzbuf, stt, n);
+                       (const double*)part, dot_n, part + 2 * kDotBlocks, (const double*)rzbuf, stt, n);
     hipLaunchKernelGGL(k_cg_step2, grid, dim3(256), 0, st, (const double*)r, pk,
                        (const double*)(part + 2 * kDotBlocks), kCgBlocks, rzbuf, stt, n);
   }

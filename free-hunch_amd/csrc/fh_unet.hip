@@ -1196,13 +1196,20 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ 
 // backward sums - is folded into per-thread constants once and the loop is load / 4 FMAs (+ SiLU) / store.
 //   forward :  y  = act(x * A + Bc),   A = rstd*gamma*(1+scale),  Bc = (beta - mean*rstd*gamma)*(1+scale) + shift
 //   backward:  dx (+)= rstd * (g - a - xhat * b),  g = dy * act'(t) * (1+scale) * gamma,  (a, b) = sums
+// Backward extras (null / 0 = off): `add2` - a second addend with x's layout (the gradient of a skip tensor that the
+// reference adds at the skip's push point, folded into the pass that produces the other addend); `out2` / `csplit` - the
+// result is written as TWO tensors, channels [0, csplit) to out ([.., csplit]) and [csplit, C) to out2 ([.., C - csplit]):
+// the torch.cat of the decoder input splits its gradient without a copy pass (csplit % 4 == 0).
 template <int BWD>
 __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, const float* __restrict__ dy,
                                                    const float* __restrict__ stats, const float* __restrict__ sums,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    int ss_stride, float* __restrict__ out, int P, int C, int act,
-                                                   int accumulate, int nchunks, int kGnChunk) {
+                                                   int accumulate, int nchunks, int kGnChunk,
+                                                   const float* __restrict__ acc_src = nullptr,
+                                                   const float* __restrict__ add2 = nullptr, float* __restrict__ out2 = nullptr,
+                                                   int csplit = 0) {
   const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   const int cg = C / 32, c4n = C / 4;
   const int p0 = chunk * kGnChunk;
@@ -1237,7 +1244,14 @@ __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, 
         xv[u] = *reinterpret_cast<const float4*>(x + idx);
         if (BWD) {
           gv[u] = *reinterpret_cast<const float4*>(dy + idx);
-          if (accumulate) ov[u] = *reinterpret_cast<const float4*>(out + idx);
+          if (accumulate) ov[u] = *reinterpret_cast<const float4*>((acc_src != nullptr ? acc_src : out) + idx);
+          if (add2 != nullptr) {
+            const float4 t2 = *reinterpret_cast<const float4*>(add2 + idx);
+            if (accumulate)
+              ov[u].x += t2.x, ov[u].y += t2.y, ov[u].z += t2.z, ov[u].w += t2.w;
+            else
+              ov[u] = t2;
+          }
         }
       }
 #pragma unroll
@@ -1265,9 +1279,14 @@ __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, 
               g *= sg * (1.f + t * (1.f - sg));
             }
             g *= gsc[e];
-            o[e] = (accumulate ? os[e] : 0.f) + rstd[e] * (g - sa[e] - xh * sb[e]);
+            o[e] = ((accumulate || add2 != nullptr) ? os[e] : 0.f) + rstd[e] * (g - sa[e] - xh * sb[e]);
           }
         }
+        if (BWD && out2 != nullptr) {
+          const int64_t pix = (int64_t)n * P + pb + u * lanes_p;
+          float* dst = 4 * c4 < csplit ? out + pix * csplit + 4 * c4 : out2 + pix * (C - csplit) + (4 * c4 - csplit);
+          *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else
         *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
@@ -1818,6 +1837,41 @@ int fh_groupnorm_bwd_apply(const float* x, const float* dy, const float* stats, 
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
   hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, (hipStream_t)stream, x, dy, stats, sums, gamma, beta,
                      scale, shift, ss_stride, dx, P, C, act, accumulate, nchunks, kGnChunk);
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// the two reductions of fh_groupnorm_bwd alone: sums [N][32][2] = (mean g, mean g xhat)
+int fh_groupnorm_bwd_sums(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                          const float* scale, const float* shift, int ss_stride, float* sums, double* scratch, int N, int P,
+                          int C, int act, void* stream) {
+  if (!x || !dy || !stats || !gamma || !beta || !sums || !scratch || C % 32 != 0) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int kGnChunk = gn_chunk(N, P);
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
+                     ss_stride, scratch, P, C, act, nchunks, kGnChunk);
+  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, st, (const double*)scratch, sums, nchunks,
+                     (double)P * (C / 32));
+  FH_LAUNCH_CHECK();
+  return 0;
+}
+
+// fh_groupnorm_bwd_apply with the two extras of k_gn_stream<1>: acc_src (addend read from another tensor than dx), add2 (a
+// second addend) and the split destination (dx: [.., csplit], dx2: [.., C - csplit]); any of them may be null / 0
+int fh_groupnorm_bwd_apply_ex(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
+                              const float* beta, const float* scale, const float* shift, int ss_stride, const float* acc_src,
+                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, void* stream) {
+  if (!x || !dy || !stats || !sums || !gamma || !beta || !dx || C % 32 != 0) return FH_EINVAL;
+  if (dx2 != nullptr && (csplit <= 0 || csplit >= C || csplit % 4 != 0)) return FH_EINVAL;
+  if (dx2 == nullptr && acc_src != nullptr && acc_src != dx) {
+    // (without a split the addend may still come from elsewhere: dx is written, acc_src only read)
+  }
+  const int kGnChunk = gn_chunk(N, P);
+  const int nchunks = (P + kGnChunk - 1) / kGnChunk;
+  hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, (hipStream_t)stream, x, dy, stats, sums, gamma, beta,
+                     scale, shift, ss_stride, dx, P, C, act, acc_src != nullptr ? 1 : 0, nchunks, kGnChunk, acc_src, add2, dx2,
+                     csplit);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -277,29 +277,31 @@ class HipOps:
             return out, stats
         return self._conv(conv_name, self._gn_apply(gn_name, x, stats, act, scale, shift), res=res), stats
 
-    def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None):
-        N, H, W, C = x.shape
-        pre = getattr(dy, "_fh_gn_sums", None)
-        if pre is not None:  # the two sums came out of the producing input-gradient convolution: streaming pass only
-            dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
-            ss = 0 if scale is None else scale.stride(0)
-            _lib.check(self.lib.fh_groupnorm_bwd_apply(
-                x.data_ptr(), dy.data_ptr(), stats.data_ptr(), pre.data_ptr(), self.P[name + ".weight"].data_ptr(),
-                self.P[name + ".bias"].data_ptr(), None if scale is None else scale.data_ptr(),
-                None if shift is None else shift.data_ptr(), ss, dx.data_ptr(), N, H * W, C, int(act),
-                int(accumulate_into is not None), _lib.stream()), "gn_bwd_apply")
-            return dx
-        sums = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
-        dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
+    def _gn_bwd(self, name, x, stats, dy, act, scale=None, shift=None, accumulate_into=None, add2=None, split=None):
+        """dL/dx of GroupNorm(+scale-shift)(+SiLU) given dL/dy.  `accumulate_into`: the gradient arriving over the block's
+        skip path is added (in place unless `split`); `add2`: one more addend (the gradient of a U-Net skip tensor forked at
+        this point); `split` = (Ca, Cb): the result is returned as two tensors [.., Ca], [.., Cb] (x was a channel concat)."""
+        N, H, W, C_ = x.shape
         ss = 0 if scale is None else scale.stride(0)
-        _lib.check(self.lib.fh_groupnorm_bwd(
-            x.data_ptr(), dy.data_ptr(), stats.data_ptr(), self.P[name + ".weight"].data_ptr(),
-            self.P[name + ".bias"].data_ptr(), None if scale is None else scale.data_ptr(),
-            None if shift is None else shift.data_ptr(), ss, sums.data_ptr(), scratch.data_ptr(), dx.data_ptr(), N, H * W, C,
-            int(act),
-            int(accumulate_into is not None), _lib.stream()), "gn_bwd")
-        return dx
+        gp = (self.P[name + ".weight"].data_ptr(), self.P[name + ".bias"].data_ptr(),
+              None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), ss)
+        sums = getattr(dy, "_fh_gn_sums", None)  # left by the producing input-gradient convolution's epilogue
+        if sums is None:
+            sums = torch.empty(N, 32, 2, dtype=torch.float32, device=x.device)
+            scratch = torch.empty(self.lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=x.device)
+            _lib.check(self.lib.fh_groupnorm_bwd_sums(x.data_ptr(), dy.data_ptr(), stats.data_ptr(), *gp, sums.data_ptr(),
+                                                      scratch.data_ptr(), N, H * W, C_, int(act), _lib.stream()), "gn_bwd_sums")
+        acc = accumulate_into
+        if split is not None:
+            dx = torch.empty(N, H, W, split[0], dtype=torch.float32, device=x.device)
+            dx2 = torch.empty(N, H, W, split[1], dtype=torch.float32, device=x.device)
+        else:
+            dx, dx2 = (acc if acc is not None else torch.empty_like(x)), None
+        _lib.check(self.lib.fh_groupnorm_bwd_apply_ex(
+            x.data_ptr(), dy.data_ptr(), stats.data_ptr(), sums.data_ptr(), *gp, None if acc is None else acc.data_ptr(),
+            None if add2 is None else add2.data_ptr(), dx.data_ptr(), None if dx2 is None else dx2.data_ptr(),
+            0 if split is None else split[0], N, H * W, C_, int(act), _lib.stream()), "gn_bwd_apply")
+        return dx if split is None else (dx, dx2)
 
     def _resample(self, x, mode):
         N, H, W, C = x.shape
@@ -361,7 +363,7 @@ class HipOps:
         tape.append(("res", op, p, x, st0, h1, st1, scale, shift))
         return out
 
-    def _res_bwd(self, rec, g):
+    def _res_bwd(self, rec, g, add2=None, split=None):
         _, op, p, x, st0, h1, st1, scale, shift = rec
         g_h2 = self._dgrad(p + ".out_layers.3", g, gn=(p + ".out_layers.0", h1, st1, 1, scale, shift))
         g_h1 = self._gn_bwd(p + ".out_layers.0", h1, st1, g_h2, 1, scale, shift)
@@ -373,7 +375,7 @@ class HipOps:
         elif op == "res_up":
             g_h0, g_xs = self._resample(g_h0, 3), self._resample(g_xs, 3)
         # (identity skip, no resampling: g_xs aliases g; every read of g is already enqueued on this stream)
-        return self._gn_bwd(p + ".in_layers.0", x, st0, g_h0, 1, accumulate_into=g_xs)
+        return self._gn_bwd(p + ".in_layers.0", x, st0, g_h0, 1, accumulate_into=g_xs, add2=add2, split=split)
 
     def _attn_geometry(self, N, T, C, heads):
         ch = C // heads
@@ -402,7 +404,7 @@ class HipOps:
         tape.append(("attn", p, x, st, qkv, S, heads))
         return out
 
-    def _attn_bwd(self, rec, g):
+    def _attn_bwd(self, rec, g, add2=None):
         _, p, x, st, qkv, S, heads = rec
         N, H, W, C = x.shape
         T = H * W
@@ -425,7 +427,7 @@ class HipOps:
         self._bgemm(dP.data_ptr(), base + qo * fs, dbase + ko * fs, T, ch, T, T, 3 * C, 3 * C, 1, 1, B_, heads, sS, s3, s3,
                     alpha)
         g_hn = self._dgrad(p + ".qkv", dqkv, gn=(p + ".norm", x, st, 0, None, None))
-        return self._gn_bwd(p + ".norm", x, st, g_hn, 0, accumulate_into=g)
+        return self._gn_bwd(p + ".norm", x, st, g_hn, 0, accumulate_into=g, add2=add2)
 
     # ---------------------------------------------------------------- whole network
     def forward_tape(self, steps, x_nchw, emb):
@@ -488,27 +490,47 @@ class HipOps:
         _lib.check(self.lib.fh_layout_nchw_nhwc(g_nchw.contiguous().data_ptr(), g.data_ptr(), N, Co, H * W, cp, 1, st),
                    "layout")
         pending = []  # gradients of skip tensors, to be added when their `push` is reached
-        for rec in reversed(tape):
+        recs = list(reversed(tape))
+        presplit = None   # (ga, gb) when the block before a pop_cat already wrote the concat's gradient as two tensors
+        skip_push = False
+        fold = os.environ.get("FH_GLUE_FOLD", "1") != "0"
+        for ri, rec in enumerate(recs):
             kind = rec[0]
+            nxt = recs[ri + 1] if ri + 1 < len(recs) else (None,)
             if kind == "out":
                 _, h, stn = rec
                 g = self._dgrad("out.2", g)
                 g = self._gn_bwd("out.0", h, stn, g, 1)
-            elif kind == "res":
-                g = self._res_bwd(rec, g)
-            elif kind == "attn":
-                g = self._attn_bwd(rec, g)
+            elif kind in ("res", "attn"):
+                # the last pass of a block's backward (GroupNorm backward of its first norm) also does the glue around it:
+                # + the skip gradient when the block's input was forked by a `push`, or the split of a concat's gradient
+                add2 = pending.pop() if (fold and nxt[0] == "push") else None
+                skip_push = add2 is not None
+                if kind == "res":
+                    split = (nxt[1], nxt[2]) if (fold and nxt[0] == "pop_cat" and nxt[1] % 4 == 0) else None
+                    g = self._res_bwd(rec, g, add2=add2, split=split)
+                    if split is not None:
+                        presplit, g = g, None
+                else:
+                    g = self._attn_bwd(rec, g, add2=add2)
             elif kind == "pop_cat":
                 _, Ca, Cb = rec
-                Nn, Hh, Ww, _ = g.shape
-                ga = torch.empty(Nn, Hh, Ww, Ca, dtype=torch.float32, device=g.device)
-                gb = torch.empty(Nn, Hh, Ww, Cb, dtype=torch.float32, device=g.device)
-                _lib.check(self.lib.fh_concat_channels(ga.data_ptr(), gb.data_ptr(), g.data_ptr(), Nn * Hh * Ww, Ca, Cb,
-                                                       1, st), "split")
+                if presplit is not None:
+                    ga, gb = presplit
+                    presplit = None
+                else:
+                    Nn, Hh, Ww, _ = g.shape
+                    ga = torch.empty(Nn, Hh, Ww, Ca, dtype=torch.float32, device=g.device)
+                    gb = torch.empty(Nn, Hh, Ww, Cb, dtype=torch.float32, device=g.device)
+                    _lib.check(self.lib.fh_concat_channels(ga.data_ptr(), gb.data_ptr(), g.data_ptr(), Nn * Hh * Ww, Ca, Cb,
+                                                           1, st), "split")
                 pending.append(gb)
                 g = ga
             elif kind == "push":
-                g = self._add(g, pending.pop())
+                if skip_push:
+                    skip_push = False
+                else:
+                    g = self._add(g, pending.pop())
             elif kind == "down_conv":  # stride-2 convolution: zero-inserted cotangent through the stride-1 input-gradient pass
                 g = self._dgrad(rec[1], self._resample(g, 4))
             elif kind == "down_pool":

@@ -335,6 +335,17 @@ int fh_groupnorm_bwd_table(const float* stats, const float* gamma, const float* 
 int fh_groupnorm_bwd_apply(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
                            const float* beta, const float* scale, const float* shift, int ss_stride, float* dx, int N, int P,
                            int C, int act, int accumulate, void* stream);
+int fh_groupnorm_bwd_sums(const float* x, const float* dy, const float* stats, const float* gamma, const float* beta,
+                          const float* scale, const float* shift, int ss_stride, float* sums, double* scratch, int N, int P,
+                          int C, int act, void* stream);
+/* The same pass with the glue of the UNet's backward folded in: dx = acc_src + add2 + (GroupNorm backward term), where acc_src
+ * (the gradient arriving over the block's skip path, openai_unet.py:256) and add2 (the gradient of a U-Net skip tensor, added
+ * by autograd where `hs.append(h)` forked it, :663-671) may each be null; with dx2 != null the result is written as two
+ * tensors, channels [0, csplit) -> dx [.., csplit] and [csplit, C) -> dx2 [.., C - csplit] - the gradient of
+ * th.cat([h, hs.pop()], dim=1) (:682) without a split pass. */
+int fh_groupnorm_bwd_apply_ex(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
+                              const float* beta, const float* scale, const float* shift, int ss_stride, const float* acc_src,
+                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with a thin output, Cout <= 8 (the 128 -> 6 output convolution and the
  * 128 -> 3 input gradient of the first one): direct form, w [Cout][9][Cin] as for fh_conv2d_nhwc, Cin % 32 == 0. */
