@@ -481,7 +481,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=30)
     ap.add_argument("--solver", default="heun")
     ap.add_argument("--unet-backend", default=os.environ.get("FH_UNET_BACKEND", "hip"))
-    ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+    ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
                     help="bf16: reduced-precision torso (non-parity speed mode, reported separately from the fp32 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=2, help="real UNet calls timed by the CPU-baseline leg")
@@ -536,7 +536,9 @@ def main():
             "value": round(total_images / elapsed, 5), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16-compute UNet convolutions (NON-PARITY mode), f32 elsewhere" if a.unet_dtype == "bf16" else
+            "dtype": ("fp16-compute UNet convolutions (the reference's use_fp16 torso arithmetic; NON-PARITY mode), f32 elsewhere"
+                      if a.unet_dtype == "fp16" else
+                      "bf16-compute UNet convolutions (NON-PARITY mode), f32 elsewhere" if a.unet_dtype == "bf16" else
                       "UNet convolutions as 3 bf16 products of 2-plane operands (~2^-16, NON-PARITY mode), f32 elsewhere"
                       if a.unet_dtype == "bf16x3" else
                       "f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy)"

@@ -271,11 +271,26 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r;
 }
 
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// the 16-bit pattern of x rounded to half precision, carried in a __bf16 slot (LDS tiles and fragments are typed __bf16)
+__device__ __forceinline__ __bf16 half_bits(float x) {
+  const _Float16 h = (_Float16)x;
+  return __builtin_bit_cast(__bf16, h);
+}
+template <bool F16>
+__device__ __forceinline__ float16_t mfma16(bf16x8_t a, bf16x8_t b, float16_t c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // NP = 3: the exact split above (six products).  NP = 2: the two leading planes, three products (h h' + h m' + m h'):
 // operands carried to 2^-17, product terms below 2^-16 dropped - between TF32 (2^-11, the default convolution arithmetic of
 // the reference's CUDA path) and fp32.  NP = 1: plain bf16 compute - operands rounded to bf16 (plane 0 = rn(x)),
 // one product, fp32 accumulation: the reduced-precision mode of the UNet (fh_unet_set_precision; NOT an fp32-parity mode).
-template <int MI, int NI, int WM, int WN, int MINW, int NP = 3>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
+// F16 (with NP = 1): the single plane holds the operands rounded to IEEE half precision (11-bit significand) and the product
+// runs on v_mfma_f32_32x32x16_f16 - the arithmetic of the reference's use_fp16 torso (openai_fp16_util.py:15-32: convolution
+// weights and inputs in float16), with fp32 accumulation and fp32 storage between the layers.
+template <int MI, int NI, int WM, int WN, int MINW, int NP = 3, bool F16 = false>  // WM x WN waves, each MI x NI accumulator tiles of 32 x 32
 __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
   constexpr int T = 64 * WM * WN;
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -365,6 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
         const float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
         __bf16 h, m, l;
         split3(x, h, m, l);
+        if (F16) h = half_bits(x);
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
         }
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);  // h h'
+        t = mfma16<F16>(af[0][i], bfr[0][j], t);  // h h'
         acc[i][j] = t;
       }
   }
@@ -486,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // buffers, issued a tap ahead and retired by the single barrier of the tap (one barrier per tap instead of two).  The DMA
 // image is lane-linear (64-byte rows, no padding), so the bank spread of the 16-byte fragment reads comes from a swizzle of
 // the 16-byte chunk index with bits 2..3 of the row, applied on the per-lane SOURCE address and on the read.
-template <int SEGW, bool NORM = false, int BM = 128, int NP = 3, bool GL = false>  // SEGW: pixels per row segment of the tile (W, capped at BM)
+template <int SEGW, bool NORM = false, int BM = 128, int NP = 3, bool GL = false, bool F16 = false>  // SEGW: pixels per row segment of the tile (W, capped at BM)
 __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   constexpr int MI = 2, NI = 1, WN = 4, T = 4 * BM;
   constexpr int NSEG = BM / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
@@ -605,6 +621,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
         }
         __bf16 h, m, l;
         split3(x, h, m, l);
+        if (F16) h = half_bits(x);
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
@@ -657,7 +674,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
           }
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], t, 0, 0, 0);
+          t = mfma16<F16>(af[0][i], bfr[0][j], t);
           acc[i][j] = t;
         }
     }
@@ -1418,19 +1435,21 @@ extern "C" {
 // (operands rounded to bf16, one product, fp32 accumulation) - the reduced-precision UNet mode, the counterpart of the
 // reference's use_fp16 torso (training/openai_fp16_util.py:15-32).  Process-wide: set before a forward / VJP.
 static int g_conv_np = 3;
-#define X6_DISPATCH(K1, K2, K3, ...)                 \
+#define X6_DISPATCH(K1, K2, K3, K16, ...)             \
   do {                                               \
     if (g_conv_np == 1)                              \
       hipLaunchKernelGGL(K1, __VA_ARGS__);           \
     else if (g_conv_np == 2)                         \
       hipLaunchKernelGGL(K2, __VA_ARGS__);           \
+    else if (g_conv_np == 16)                        \
+      hipLaunchKernelGGL(K16, __VA_ARGS__);          \
     else                                             \
       hipLaunchKernelGGL(K3, __VA_ARGS__);           \
   } while (0)
 
 int fh_unet_set_precision(int mode) {
-  if (mode < 0 || mode > 2) return FH_EINVAL;
-  g_conv_np = mode == 0 ? 3 : (mode == 1 ? 1 : 2);
+  if (mode < 0 || mode > 3) return FH_EINVAL;
+  g_conv_np = mode == 0 ? 3 : (mode == 1 ? 1 : (mode == 2 ? 2 : 16));  // 16: one half-precision plane on the f16 MFMA
   return 0;
 }
 
@@ -1558,32 +1577,32 @@ static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, co
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
     static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;  // weight tile by LDS-DMA (default; 0 = register staging, the A/B switch)
     if (big && glds && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), (k_conv_x6r<256, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), (k_conv_x6r<128, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), (k_conv_x6r<64, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), (k_conv_x6r<256, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), (k_conv_x6r<128, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 2>), (k_conv_x6r<64, false, 256, 3>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 2>), (k_conv_x6r<64, false, 256, 3>), (k_conv_x6r<64, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
     else if (r3 && W % 128 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 2>), (k_conv_x6r<128, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 2>), (k_conv_x6r<128, false, 128, 3>), (k_conv_x6r<128, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 64 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 2>), (k_conv_x6r<64, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 2>), (k_conv_x6r<64, false, 128, 3>), (k_conv_x6r<64, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 32 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 2>), (k_conv_x6r<32, false, 128, 3>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 2>), (k_conv_x6r<32, false, 128, 3>), (k_conv_x6r<32, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else
-      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
   } else if (ksplit > 1 && Cout > 64 && b128 * ksplit >= 256 && !getenv("FH_X6_NOBIGSPLIT")) {
     // small grids: 128 x 128 tiles (21 flop per byte pulled from L2 instead of 12.8) once split-K still fills the chip
-    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
-    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 2>), (k_conv_x6<1, 2, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 2>), (k_conv_x6<1, 2, 2, 2, 2, 3>), (k_conv_x6<1, 2, 2, 2, 2, 1, true>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
-    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 2>), (k_conv_x6<1, 1, 2, 2, 2, 3>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 2>), (k_conv_x6<1, 1, 2, 2, 2, 3>), (k_conv_x6<1, 1, 2, 2, 2, 1, true>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
   }
   if (ksplit > 1) {
     const int64_t total = M * Cout;
@@ -1666,23 +1685,23 @@ static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, 
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
   static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;
   if (big && glds && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), (k_conv_x6r<256, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), (k_conv_x6r<128, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), (k_conv_x6r<64, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), (k_conv_x6r<256, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), (k_conv_x6r<128, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 2>), (k_conv_x6r<64, true, 256, 3>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 2>), (k_conv_x6r<64, true, 256, 3>), (k_conv_x6r<64, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
   else if (W % 128 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 2>), (k_conv_x6r<128, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 2>), (k_conv_x6r<128, true, 128, 3>), (k_conv_x6r<128, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
   else if (W == 64)
-    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 2>), (k_conv_x6r<64, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 2>), (k_conv_x6r<64, true, 128, 3>), (k_conv_x6r<64, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
   else
-    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 2>), (k_conv_x6r<32, true, 128, 3>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 2>), (k_conv_x6r<32, true, 128, 3>), (k_conv_x6r<32, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -10,8 +10,8 @@ class iDDPMLinearPrecond(torch.nn.Module):
     def __init__(self, model, img_resolution, img_channels, label_dim=0, use_fp16=False, beta_min=0.0001,
                  beta_max=0.02, M=1000, **model_kwargs):
         super().__init__()
-        if use_fp16:  # the reference casts the torso and its input to fp16 (:171); here: bf16-compute convolutions
-            model.set_dtype("bf16")
+        if use_fp16:  # the reference casts the torso and its input to fp16 (:171): half-precision convolution operands
+            model.set_dtype("fp16")
         self.use_fp16 = use_fp16
         self.img_resolution, self.img_channels, self.label_dim = img_resolution, img_channels, label_dim
         self.beta_min, self.beta_max, self.M, self.model = beta_min, beta_max, M, model

@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 
-_PRECISION_MODE = {"fp32": 0, "bf16": 1, "bf16x3": 2}  # fh_unet_set_precision codes
+_PRECISION_MODE = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp16": 3}  # fh_unet_set_precision codes
 
 
 @dataclass
@@ -263,18 +263,17 @@ class UNetModel(torch.nn.Module):
 
     def set_dtype(self, dtype):
         """"fp32" (default): every convolution has fp32 accuracy (exact 3-way bf16 split on the matrix cores).
-        "bf16": reduced-precision torso - convolution operands rounded to bf16, fp32 accumulation, everything else
-        (GroupNorm, attention, residuals, storage) stays fp32.  This is the counterpart of the reference's `use_fp16` torso
-        (training/openai_fp16_util.py:15-32); "fp16" is accepted as an alias: gfx950 runs bf16 and fp16 MFMAs at the same
-        rate and bf16 keeps the fp32 exponent range.  Outside the fp32 parity bar - reported as a separate mode.
+        "fp16": the reference's `use_fp16` torso (training/openai_fp16_util.py:15-32, openai_unet.py:464, 625-638): the
+        convolutions of the input / middle / output blocks multiply operands rounded to IEEE half precision (weights once,
+        activations while they are staged) on v_mfma_f32_32x32x16_f16 with fp32 accumulation; GroupNorm, softmax, the time
+        embedding and the first / last layers stay fp32 as in the reference, and so does the STORAGE between layers (the
+        reference stores half there: one more rounding per tensor).  Pinned to the reference's own fp16 output
+        (tests/golden/unet_a_fp16.npz).  Outside the fp32 parity bar - reported as a separate mode.
+        "bf16": the same with operands rounded to bfloat16 (8-bit significand, fp32 exponent range; same MFMA rate).
         "bf16x3": operands carried as two bf16 planes, three matrix products per convolution (relative error ~ 2^-16, i.e.
         between TF32 - what the reference's convolutions run in by default on its CUDA path - and fp32) at half the
         matrix work of "fp32".  Also reported separately."""
-        if dtype == "fp16":
-            import warnings
-            warnings.warn("unet dtype fp16 -> bf16 compute (same MFMA rate on gfx950, fp32 exponent range)")
-            dtype = "bf16"
-        if dtype not in ("fp32", "bf16", "bf16x3"):
+        if dtype not in _PRECISION_MODE:
             raise ValueError(f"unet dtype must be fp32, bf16x3, bf16 or fp16, got {dtype}")
         if dtype != "fp32" and self.backend != "hip":
             raise NotImplementedError("the reduced-precision torso exists on the hip backend only")
@@ -348,7 +347,7 @@ def create_model(image_size, num_channels, num_res_blocks, channel_mult="", lear
     cm = tuple(int(c) for c in channel_mult.split(",")) if channel_mult else ()
     cfg = UNetConfig(image_size, num_channels, num_res_blocks, cm, learn_sigma, attention_resolutions, num_heads,
                      num_head_channels, use_scale_shift_norm, resblock_updown, use_new_attention_order)
-    return UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("bf16" if use_fp16 else "fp32"))
+    return UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("fp16" if use_fp16 else "fp32"))
 
 
 def load_model(state_dict_path, setup_path, backend="hip", dtype=None):
@@ -357,7 +356,7 @@ def load_model(state_dict_path, setup_path, backend="hip", dtype=None):
     with open(setup_path) as f:
         cfg, fp16 = config_from_setup_text(f.read())
     # `use_fp16 True` in the setup file selects the reduced-precision torso, as in the reference (openai_loading_utils.py)
-    model = UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("bf16" if fp16 else "fp32"))
+    model = UNetModel(cfg, backend=backend, dtype=dtype if dtype is not None else ("fp16" if fp16 else "fp32"))
     model.load_state_dict(sd)
     return model, cfg
 

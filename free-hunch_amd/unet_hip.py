@@ -58,6 +58,13 @@ def _split3(w):
     return torch.stack([h, m, lo]).reshape(3, rows, taps, k // _K, _K).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def _half_plane(w):
+    """fp32 [rows][taps][K] -> the half-precision bit patterns in the split-bf16 kernels' weight layout, ONE plane
+    [1][taps][K/32][rows][32] (int16 storage; the fp16 mode of fh_unet_set_precision reads it through the f16 MFMA)."""
+    rows, taps, k = w.shape
+    return w.to(torch.float16).view(torch.int16).reshape(1, rows, taps, k // _K, _K).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def _use_x6(N, H, W, rows_out):
     """Measured on MI355X (profiles/tools/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (1.05-1.1x the
     Winograd one) on the large layers and, with the same deterministic split-K, 1.0-1.2x on the 8 x 8 ... 32 x 32 grids;
@@ -87,8 +94,17 @@ class _Conv:
         if kh == 3 and kw == 3 and CONV_MODE == "wino":
             self.wu_f = _wino(wf.reshape(co, 3, 3, self.ci_p))
             self.wu_d = _wino(wd.reshape(ci, 3, 3, self.co_p))
+        self.wh_f = self.wh_d = None  # half-precision planes, built when the fp16 mode is first used
         if CONV_MODE == "x6":  # exact bf16 split of both copies (6 bytes per weight)
             self.wx_f, self.wx_d = _split3(self.wf), _split3(self.wd)
+
+    def planes(self, fwd, fp16):
+        """the weight operand of the split-bf16 kernels: the three bf16 planes, or the half-precision plane (fp16 mode)"""
+        if not fp16:
+            return self.wx_f if fwd else self.wx_d
+        if self.wh_f is None:
+            self.wh_f, self.wh_d = _half_plane(self.wf), _half_plane(self.wd)
+        return self.wh_f if fwd else self.wh_d
 
 
 class HipOps:
@@ -96,7 +112,7 @@ class HipOps:
         self.cfg = cfg
         self.lib = _lib.load()
         self.P = P
-        self.bf16 = False  # reduced-precision torso (UNetModel.set_dtype): convolution operands rounded to bf16
+        self.bf16 = 0  # fh_unet_set_precision code of the torso (UNetModel.set_dtype): 0 fp32-exact, 1 bf16, 2 bf16x3, 3 fp16
         self.conv = {}
         for k, v in P.items():
             if k.endswith(".weight") and v.dim() >= 3:
@@ -117,7 +133,7 @@ class HipOps:
             out = torch.empty(N, Ho, Wo, c.co, dtype=torch.float32, device=x.device)
             ks = self.lib.fh_conv2d_splitk(N, Ho, Wo, Ci, c.co, c.kh, c.kw)
             ws = torch.empty(ks, N * Ho * Wo, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
-            fn, wgt = ((self.lib.fh_conv2d_x6_nhwc, c.wx_f) if c.wx_f is not None and _use_x6(N, Ho, Wo, c.co)
+            fn, wgt = ((self.lib.fh_conv2d_x6_nhwc, c.planes(True, self.bf16 == 3)) if c.wx_f is not None and _use_x6(N, Ho, Wo, c.co)
                        else (self.lib.fh_conv2d_nhwc, c.wf))
             _lib.check(fn(x.data_ptr(), wgt.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(),
                           out.data_ptr(), None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh, c.kw, pad,
@@ -138,7 +154,7 @@ class HipOps:
         if c.wx_f is not None and _use_x6(N, H, W, c.co):
             # group-sum epilogue: the statistics of a GroupNorm applied to this output come out of the convolution itself
             epi, keep = self._epilogue(ks, N, H, W, Ci, c.co, c.kh, c.kw, pad, 0)
-            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), c.wx_f.data_ptr(), b.data_ptr(),
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), c.planes(True, self.bf16 == 3).data_ptr(), b.data_ptr(),
                                                      None if res is None else res.data_ptr(), out.data_ptr(),
                                                      None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh,
                                                      c.kw, pad, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc")
@@ -177,7 +193,7 @@ class HipOps:
             epi, keep = (None, None)
             if gn is not None and gn[1].shape == out.shape:
                 epi, keep = self._epilogue(ks, N, H, W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1, gn)
-            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(g.data_ptr(), c.wx_d.data_ptr(), None,
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(g.data_ptr(), c.planes(False, self.bf16 == 3).data_ptr(), None,
                                                      None if res is None else res.data_ptr(), out.data_ptr(),
                                                      None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p, c.ci, c.kh,
                                                      c.kw, c.kh // 2, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc(dgrad)")
@@ -268,7 +284,8 @@ class HipOps:
                 table.data_ptr(), N, Ci, _lib.stream()), "gn_table")
             out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
             epi, keep = self._epilogue(1, N, H, W, Ci, c.co, 3, 3, 1, 0)
-            _lib.check(self.lib.fh_conv2d_x6_norm_nhwc_gn(x.data_ptr(), table.data_ptr(), int(act), c.wx_f.data_ptr(),
+            _lib.check(self.lib.fh_conv2d_x6_norm_nhwc_gn(x.data_ptr(), table.data_ptr(), int(act),
+                                                          c.planes(True, self.bf16 == 3).data_ptr(),
                                                           c.b.data_ptr(), None if res is None else res.data_ptr(),
                                                           out.data_ptr(), N, H, W, Ci, c.co, epi, _lib.stream()),
                        "fh_conv2d_x6_norm_nhwc")

@@ -283,7 +283,9 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
  * fp32 accumulation) - the reduced-precision UNet mode, counterpart of the reference's fp16 torso
  * (training/openai_fp16_util.py:15-32, flag path openai_preconditioning.py:171); 2 = the two leading bf16 planes of both
  * operands, three products (relative error ~ 2^-16: between TF32, the default convolution arithmetic of the reference's
- * CUDA path, and fp32) - half the matrix work of mode 0.  Process-wide. */
+ * CUDA path, and fp32) - half the matrix work of mode 0; 3 = the reference's fp16 torso arithmetic: operands rounded to IEEE
+ * half precision, one product on v_mfma_f32_32x32x16_f16, fp32 accumulation (the weight operand is then ONE plane of
+ * half-precision bit patterns in the same [taps][Cin/32][Cout][32] layout).  Process-wide. */
 int fh_unet_set_precision(int mode);
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 

@@ -493,15 +493,16 @@ def test_free_running_converged_256_within_1e3(dev, gold, tag):
       * a denoiser that does not amplify: the closed-form Gaussian-prior denoiser (`*_gauss`: exercises the whole Free Hunch
         path, all calls on the vjp branch) or the HIP UNet with a damped output layer (`*_damped`: UNet forward + input-VJP
         through the clamp, both branches).
-    Asserted: identical k and branch lists, per-call CG iteration counts within 2 % + 2 (converged counts move by a few
-    iterations with the summation order), and the final image within 1e-3 max-abs of the reference's."""
+    Asserted: identical k and branch lists, per-call CG iteration counts within 4 % + 2 (the count of a converged solve at
+    cond ~ 1e6 moves with the summation order of its dot products: measured up to 2.5 % over two versions of the p.Ap
+    reduction), and the final image within 1e-3 max-abs of the reference's (measured 3e-6 .. 1.4e-4)."""
     g = gold("trajectories256_tight")
     p = tag + "__"
     net = nets.gauss_net(256, dev) if str(g[p + "net"]) == "gauss" else nets.damped_hip_net(inputs.SMALL_C, int(g["unet_seed"]), dev)
     rec, tr = _free_run(g, tag, 256, net, dev, DATA, 2, "hip-" + str(g[p + "net"]))
     assert rec["k_equal"], rec
     assert rec["branch_mismatch_calls"] == 0, rec
-    assert all(abs(a - b) <= 0.02 * b + 2 for a, b in zip(rec["niter_hip"], rec["niter_ref"])), rec
+    assert all(abs(a - b) <= 0.04 * b + 2 for a, b in zip(rec["niter_hip"], rec["niter_ref"])), rec
     assert rec["final_max_abs"] < 1e-3, rec
     assert abs(float(g[p + "x_final_absmax"]) - rec["ref_abs_max"]) < 1.0  # (the strided sample is representative)
 
