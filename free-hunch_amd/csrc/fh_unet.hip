@@ -207,7 +207,10 @@ struct ConvArgsX {
   int gn_mode, gn_act, gn_chunks;
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + __expf(-v)); }
+// SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions): the fused-input convolution
+// evaluates it while staging its activation tile, where every VALU cycle is exposed; the stand-alone apply kernel uses the
+// same function, so the two paths stay bit-identical
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 // Group-sum epilogue of the split-bf16 convolutions.  A lane of the 32 x 32 MFMA layout holds 16 rows x MI tiles of ONE output
 // channel per column tile j, so the sums of a channel are formed in registers (double), the two lane halves are folded with a
@@ -1182,18 +1185,26 @@ __global__ __launch_bounds__(256) void k_gn_partial(const float* __restrict__ x,
   if (threadIdx.x < 64) partial[(int64_t)blockIdx.x * 64 + threadIdx.x] = acc[threadIdx.x];
 }
 
-// MODE 0 -> (mean, rstd);  MODE 1 -> (mean g, mean g*xhat)
+// MODE 0 -> (mean, rstd);  MODE 1 -> (mean g, mean g*xhat).  One workgroup of 1024 threads per image: 16 row groups x 64
+// slots, so a thread adds nchunks / 16 partials (the convolution epilogues leave up to 512 chunks per image); fixed order.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ partial, float* __restrict__ out,
-                                                     int nchunks, double count) {
-  __shared__ double red[4][64];
-  const int n = blockIdx.x, slot = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
-  double s = 0.0;
-  for (int c = lane4; c < nchunks; c += 4) s += partial[((int64_t)n * nchunks + c) * 64 + slot];
-  red[lane4][slot] = s;
+__global__ __launch_bounds__(1024) void k_gn_finalize(const double* __restrict__ partial, float* __restrict__ out,
+                                                      int nchunks, double count) {
+  __shared__ double red[16][64];
+  const int n = blockIdx.x, slot = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  double s0 = 0.0, s1 = 0.0;
+  int c = rg;
+  for (; c + 16 < nchunks; c += 32) {
+    s0 += partial[((int64_t)n * nchunks + c) * 64 + slot];
+    s1 += partial[((int64_t)n * nchunks + c + 16) * 64 + slot];
+  }
+  if (c < nchunks) s0 += partial[((int64_t)n * nchunks + c) * 64 + slot];
+  red[rg][slot] = s0 + s1;
   __syncthreads();
   if (threadIdx.x >= 64) return;
-  s = red[0][slot] + red[1][slot] + red[2][slot] + red[3][slot];
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += red[g][slot];
   const int grp = slot >> 1, which = slot & 1;
   const double other = __shfl_xor(s, 1, 64);
   if (MODE == 1) {
@@ -1768,7 +1779,7 @@ int fh_groupnorm_stats(const float* x, float* stats, double* scratch, int N, int
   hipLaunchKernelGGL(k_gn_partial<0>, dim3(N * nchunks), dim3(256), 0, st, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0, part, P, C, 0, nchunks, kGnChunk);
-  hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(256), 0, st, (const double*)part, stats, nchunks,
+  hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(1024), 0, st, (const double*)part, stats, nchunks,
                      (double)P * (C / 32));
   FH_LAUNCH_CHECK();
   return 0;
@@ -1796,7 +1807,7 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
   double* part = scratch;
   hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
                      ss_stride, part, P, C, act, nchunks, kGnChunk);
-  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, st, (const double*)part, sums, nchunks,
+  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(1024), 0, st, (const double*)part, sums, nchunks,
                      (double)P * (C / 32));
   hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, (const float*)sums, gamma, beta,
                      scale, shift, ss_stride, dx, P, C, act, accumulate, nchunks, kGnChunk);
@@ -1809,9 +1820,9 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
 int fh_groupnorm_finalize(const double* partial, float* out, int N, int chunks, double count, int mode, void* stream) {
   if (!partial || !out || N < 1 || chunks < 1 || count <= 0 || mode < 0 || mode > 1) return FH_EINVAL;
   if (mode == 0)
-    hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, count);
+    hipLaunchKernelGGL(k_gn_finalize<0>, dim3(N), dim3(1024), 0, (hipStream_t)stream, partial, out, chunks, count);
   else
-    hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, (hipStream_t)stream, partial, out, chunks, count);
+    hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(1024), 0, (hipStream_t)stream, partial, out, chunks, count);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -1870,7 +1881,7 @@ int fh_groupnorm_bwd_sums(const float* x, const float* dy, const float* stats, c
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
   hipLaunchKernelGGL(k_gn_partial<1>, dim3(N * nchunks), dim3(256), 0, st, x, dy, stats, gamma, beta, scale, shift,
                      ss_stride, scratch, P, C, act, nchunks, kGnChunk);
-  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(256), 0, st, (const double*)scratch, sums, nchunks,
+  hipLaunchKernelGGL(k_gn_finalize<1>, dim3(N), dim3(1024), 0, st, (const double*)scratch, sums, nchunks,
                      (double)P * (C / 32));
   FH_LAUNCH_CHECK();
   return 0;
