@@ -93,6 +93,13 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     return enc.decode(x)
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (the PMC passes are re-run when a kernel changes)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r00_" + suffix)
+
+
 def roofline_cov_apply(device, m=32, iters=200, nimg=1):
     """fh_rep_apply at the headline point d = 196608, m = 32 (float64 base), events on the stream.
     nimg > 1: the batched launch the lock-step CG issues (one factor base per image, grid z = image)."""
@@ -141,7 +148,7 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
     algo_bytes = nimg * (8 * d * m + 8 * d * 4)  # per image: base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
     traffic = None  # HBM-side bytes per apply from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE), if present
-    pmc = os.path.join(ROOT, "profiles", "r02_cov_apply_pmc.json" if nimg == 1 else "r02_cov_apply_b8_pmc.json")
+    pmc = _latest_profile("cov_apply_pmc.json" if nimg == 1 else "cov_apply_b8_pmc.json")
     if m == 32 and nimg in (1, 8) and os.path.exists(pmc):
         with open(pmc) as f_:
             rec = json.load(f_)
@@ -237,7 +244,7 @@ def roofline_conv_mfma(device, iters=20):
     flops = 2.0 * N * H * W * Ci * Co * k * k
     ach = 6 * flops / t6 / 1e12
     traffic = None  # HBM-side bytes per launch from the committed PMC passes (profiles/tools/pmc_conv.sh), if present
-    pmc = os.path.join(ROOT, "profiles", "r02_conv_pmc.json")
+    pmc = _latest_profile("conv_pmc.json")
     if os.path.exists(pmc):
         with open(pmc) as f_:
             per = json.load(f_).get("traffic_bytes_per_launch", {})

@@ -12,6 +12,6 @@ tot=sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:24]:
     print("%6.2f%% %9d calls %9.1f us avg  %s" % (100*float(r["TotalDurationNs"])/tot, int(r["Calls"]), float(r["AverageNs"])/1e3, r["Name"][:110]))
 print("total kernel ms", tot/1e6)
-shutil.copy(f, "gpurun_out/r02_bench_imagenet_sr_heun30_b8_kernel_stats.csv")
+shutil.copy(f, "gpurun_out/r03_bench_imagenet_sr_heun30_b8_kernel_stats.csv")
 PY
 rm -rf gpurun_out/prof_in

@@ -28,7 +28,7 @@ for kind, key in (("fetch", "FETCH_SIZE_KiB"), ("write", "WRITE_SIZE_KiB")):
 rec["traffic_bytes_per_launch"] = {k: int(rec["FETCH_SIZE_KiB"][k] * 2048 + rec["WRITE_SIZE_KiB"].get(k, 0) * 1024) for k in rec["FETCH_SIZE_KiB"]}
 algo = sum(rec["algorithmic_bytes"].values())
 rec["traffic_over_algorithmic"] = {k: round(v / algo, 3) for k, v in rec["traffic_bytes_per_launch"].items()}
-json.dump(rec, open("gpurun_out/r02_conv_pmc.json", "w"), indent=1)
+json.dump(rec, open("gpurun_out/r03_conv_pmc.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 PY
 rm -rf $O

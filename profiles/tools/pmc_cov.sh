@@ -14,7 +14,7 @@ out = {}
 for tag, nimg in (("b8_twopass", 8), ("b1_singlesweep", 1), ("b1_twopass", 1)):
     rec = {"kernels_us": {}, "FETCH_SIZE_KiB": {}, "WRITE_SIZE_KiB": {}}
     f = glob.glob(f"gpurun_out/pmc_cov/{tag}_stats/**/*kernel_stats.csv", recursive=True)[0]
-    shutil.copy(f, f"gpurun_out/r02_cov_apply_{tag}_kernel_stats.csv")
+    shutil.copy(f, f"gpurun_out/r03_cov_apply_{tag}_kernel_stats.csv")
     for r in csv.DictReader(open(f)):
         m = re.search(r"(k_rep_[a-z0-9_]+)", r["Name"])
         if m: rec["kernels_us"][m.group(1)] = round(float(r["AverageNs"]) / 1e3, 2)
@@ -32,17 +32,17 @@ for tag, nimg in (("b8_twopass", 8), ("b1_singlesweep", 1), ("b1_twopass", 1)):
     rec["traffic_over_algorithmic"] = round((fetch + write) / (nimg * 56623104), 3)
     rec["us_per_apply_kernel_sum"] = round(sum(rec["kernels_us"].values()), 2)
     out[tag] = rec
-json.dump(out, open("gpurun_out/r02_cov_apply_pmc_all.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r03_cov_apply_pmc_all.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 # the two files bench.py reads its `traffic` from
 cmd = ["bash profiles/tools/pmc_cov.sh  (rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE as SEPARATE passes of `python3 profiles/tools/prof_cov_one.py <nimg> <exclusive>`)"]
 units = "counter values are KiB per dispatch (mean over 30 dispatches); FETCH_SIZE doubled for gfx950 wide coalesced reads (MI355X_MICROARCH.md, HBM section)"
 b8 = {"what": "fh_rep_apply_batched at d=196608, m=32, float64, 8 images per launch: the two-pass kernels the lock-step CG issues (k_rep_dots<nt> + k_rep_coef + k_rep_apply2<nt>), MI355X, rocprofv3 7.2",
       "commands": cmd, "units": units, **out["b8_twopass"],
-      "note": "1.95x the algorithmic bytes: each image's factor base is read by both passes (the counters also count Infinity-Cache hits).  The single-sweep kernel reads it once (r02_cov_apply_pmc.json) but is slower for batched launches - profiles/r02_cov_apply_single_sweep.md."}
-json.dump(b8, open("gpurun_out/r02_cov_apply_b8_pmc.json", "w"), indent=1)
+      "note": "1.95x the algorithmic bytes: each image's factor base is read by both passes (the counters also count Infinity-Cache hits).  The single-sweep kernel reads it once (r03_cov_apply_pmc.json) but is slower for batched launches - profiles/r03_cov_apply_single_sweep.md."}
+json.dump(b8, open("gpurun_out/r03_cov_apply_b8_pmc.json", "w"), indent=1)
 b1 = {"what": "fh_rep_apply at d=196608, m=32, float64, ONE image per launch on an exclusive context: the single-sweep kernel k_rep_fused<4>",
       "commands": cmd, "units": units, **out["b1_singlesweep"], "two_pass_for_comparison": out["b1_twopass"]}
-json.dump(b1, open("gpurun_out/r02_cov_apply_pmc.json", "w"), indent=1)
+json.dump(b1, open("gpurun_out/r03_cov_apply_pmc.json", "w"), indent=1)
 PY
 rm -rf $O
