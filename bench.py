@@ -249,7 +249,7 @@ def roofline_conv_mfma(device, iters=20):
         with open(pmc) as f_:
             per = json.load(f_).get("traffic_bytes_per_launch", {})
         traffic = next((v for k_, v in per.items() if k_.startswith("k_conv_x6r")), None)
-    return {"bound": "mfma", "kernel": "k_conv_x6r<256,false,256,3> 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
+    return {"bound": "mfma", "kernel": "k_conv_x6r<256,false,256,3,GL> (weight tile by LDS-DMA) 3x3 128->128 on 8x256x256 NHWC, fp32 via 6 x v_mfma_f32_32x32x16_bf16",
             "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
             "algorithmic_bytes": int(2 * N * H * W * 128 * 4 + 3 * 2 * Ci * Co * k * k),
             "flops_per_launch": 6 * flops, "us_per_launch": round(t6 * 1e6, 1),
