@@ -58,10 +58,15 @@ def build_net(arch, device, backend, dtype="fp32"):
     return iDDPMLinearPrecond(model, cfg.image_size, 3).to(device), cfg
 
 
-def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir):
-    """B independent images through the lock-step sampler; returns uint8 [B,3,S,S] on the device.  (Round 2 could split the
-    batch into several lock-step groups on separate host threads / streams; measured up to 20x slower solves - the small
-    Free Hunch kernels of one group queue behind the other group's convolutions - and removed.)"""
+def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir, groups=2):
+    """B independent images through the lock-step sampler; returns uint8 [B,3,S,S] on the device.  The batch runs as
+    `groups` lock-step groups on separate host threads / HIP streams, so that the latency-bound Free Hunch phase of one group
+    (covariance updates, CG: small kernels with dependent launches) overlaps the MFMA-bound UNet phase of the other.
+    Round 2 measured this up to 20x SLOWER: every image then had its own stream for its updates, 8 + 8 streams were multiplexed
+    onto 4 hardware queues and the small kernels sat behind convolutions of the other group in the same queue.  Since the
+    updates and the CG of a group are single batched launch sequences on the group's own stream (round 3), two groups mean two
+    streams: measured 3.43 s vs 3.82 s per batch of 8 (+11 %); four groups of two images lose again (UNet at batch 2)."""
+    from concurrent.futures import ThreadPoolExecutor
     from free_hunch_amd.measurements import get_operator
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
     enc = StandardRGBEncoder()
@@ -83,14 +88,41 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
         ys.append(op.forward(enc.encode(img[None].to(device)), noiseless=False))
         noises.append(torch.randn((1, 3, S, S), generator=torch.Generator().manual_seed(int(seed) % (1 << 31)),
                                   dtype=torch.float32))
+    B = len(ops)
     if prof:
         torch.cuda.synchronize()
         print(f"[FH_PHASE_TIMES] run_batch setup (operators, measurements, noise): {time.perf_counter() - t_setup:.3f} s", flush=True)
-    x = conditional_sampler_batched(net, torch.cat(noises, 0).to(device), ys, ops, num_steps=num_steps, sigma_min=0.002,
-                                    sigma_max=80, rho=7, solver=solver, slot_base=0, exclusive_device=True,
-                                    **fh_kwargs(data_dir, solver))
-    run_batch.cg_iters = [sum(t["niter"] for t in m.trace) for m in conditional_sampler_batched.last_mechanisms]
-    return enc.decode(x)
+    groups = max(1, min(groups, B))
+    bounds = [round(g * B / groups) for g in range(groups + 1)]
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+
+    def run_group(g):
+        lo, hi = bounds[g], bounds[g + 1]
+        torch.cuda.set_device(dev_index)
+        stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            x = conditional_sampler_batched(net, torch.cat(noises[lo:hi], 0).to(device), ys[lo:hi], ops[lo:hi],
+                                            num_steps=num_steps, sigma_min=0.002, sigma_max=80, rho=7, solver=solver,
+                                            slot_base=lo, exclusive_device=(groups == 1), **fh_kwargs(data_dir, solver))
+            out = enc.decode(x)
+            out.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return out, done, [sum(t["niter"] for t in m.trace) for m in conditional_sampler_batched.tls.mechanisms]
+
+    if groups == 1:
+        res = [run_group(0)]
+    else:
+        with ThreadPoolExecutor(max_workers=groups) as pool:
+            res = list(pool.map(run_group, range(groups)))
+    for _o, done, _n in res:
+        main.wait_event(done)
+    run_batch.cg_iters = [n for r in res for n in r[2]]
+    return torch.cat([r[0] for r in res], 0)
 
 
 def _latest_profile(suffix):
@@ -483,6 +515,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--groups", type=int, default=2,
+                    help="lock-step groups per GPU (the Free Hunch phase of one overlaps the UNet phase of the other)")
     ap.add_argument("--arch", default="ffhq", choices=["ffhq", "imagenet"])
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--num-steps", type=int, default=30)
@@ -530,7 +564,7 @@ def main():
 
     def step(i):
         seeds = [(i * world + rank) * a.batch + j for j in range(a.batch)]
-        out = run_batch(net, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir)
+        out = run_batch(net, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir, a.groups)
         exchange(out, world, coll)
         return out
 
@@ -553,7 +587,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.arch.upper()}-256 arch, {a.operator}, FH low-rank covariance (dct_diagonal), "
                                    f"num_steps={a.num_steps} {a.solver}, batch={a.batch} per GPU",
-                       "images_per_step": a.batch * world,
+                       "images_per_step": a.batch * world, "lockstep_groups_per_gpu": a.groups,
                        "unet_backend": a.unet_backend,
                        "net_calls_per_image": 2 * a.num_steps - 1 if a.solver == "heun" else a.num_steps,
                        "cg_iters_per_image_last_step": getattr(run_batch, "cg_iters", None)},

@@ -188,7 +188,7 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
 
     def _tick(name, t0):
         if prof is not None or name in sync_after:
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()  # (this group's stream only: other groups / ranks keep running)
         if prof is not None:
             prof[name] += _time.perf_counter() - t0
         return _time.perf_counter()

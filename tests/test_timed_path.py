@@ -249,3 +249,19 @@ def test_batched_covariance_updates_equal_per_image_bitwise(dev, S):
             for i, (p, q) in enumerate(zip(state(single[b]), state(batch[b]))):
                 assert torch.equal(p, q), (si, what, b, i)
     assert batch[0].famC.m == 16
+
+
+def test_two_lockstep_groups_equal_one_group(dev):
+    """bench.py's default launch: the 8 images of a GPU as TWO lock-step groups on two host threads / streams (the Free Hunch
+    phase of one group overlaps the UNet phase of the other).  With the batch-invariant Gaussian-prior denoiser the two groups
+    must reproduce the single-group run bit for bit: no scratch, context or graph cache is shared between groups."""
+    import bench
+    net = nets.gauss_net(256, dev)
+    images = bench.smooth_images(8, 256, 7)
+    outs = []
+    for groups in (1, 2):
+        outs.append(bench.run_batch(net, images, list(range(8)), "gaussian_blur", 6, "heun", dev, DATA, groups).cpu())
+        torch.cuda.synchronize()
+        if groups == 2:
+            assert len(bench.run_batch.cg_iters) == 8
+    assert torch.equal(outs[0], outs[1])
