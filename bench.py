@@ -58,14 +58,16 @@ def build_net(arch, device, backend, dtype="fp32"):
     return iDDPMLinearPrecond(model, cfg.image_size, 3).to(device), cfg
 
 
-def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir, groups=2):
+def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, data_dir, groups=1):
     """B independent images through the lock-step sampler; returns uint8 [B,3,S,S] on the device.  The batch runs as
     `groups` lock-step groups on separate host threads / HIP streams, so that the latency-bound Free Hunch phase of one group
     (covariance updates, CG: small kernels with dependent launches) overlaps the MFMA-bound UNet phase of the other.
     Round 2 measured this up to 20x SLOWER: every image then had its own stream for its updates, 8 + 8 streams were multiplexed
     onto 4 hardware queues and the small kernels sat behind convolutions of the other group in the same queue.  Since the
     updates and the CG of a group are single batched launch sequences on the group's own stream (round 3), two groups mean two
-    streams: measured 3.43 s vs 3.82 s per batch of 8 (+11 %); four groups of two images lose again (UNet at batch 2)."""
+    streams: measured 3.43 s vs 3.82 s per batch of 8 (+11 %) on runs of a few batches; four groups of two images lose again
+    (UNet at batch 2).  On a SUSTAINED run (20 steps, the chip at its power limit) the overlap buys nothing: 2.200 vs 2.195
+    images/s - the convolutions slow down by what the overlap gains - so one group stays the default."""
     from concurrent.futures import ThreadPoolExecutor
     from free_hunch_amd.measurements import get_operator
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
@@ -515,8 +517,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--groups", type=int, default=2,
-                    help="lock-step groups per GPU (the Free Hunch phase of one overlaps the UNet phase of the other)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="lock-step groups per GPU (2: the Free Hunch phase of one group overlaps the UNet phase of the other; "
+                         "+3-11 %% on runs of a few batches, nothing on a sustained, power-limited run - see run_batch)")
     ap.add_argument("--arch", default="ffhq", choices=["ffhq", "imagenet"])
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--num-steps", type=int, default=30)

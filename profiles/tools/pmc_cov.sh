@@ -39,7 +39,7 @@ cmd = ["bash profiles/tools/pmc_cov.sh  (rocprofv3 --kernel-trace --stats, --pmc
 units = "counter values are KiB per dispatch (mean over 30 dispatches); FETCH_SIZE doubled for gfx950 wide coalesced reads (MI355X_MICROARCH.md, HBM section)"
 b8 = {"what": "fh_rep_apply_batched at d=196608, m=32, float64, 8 images per launch: the two-pass kernels the lock-step CG issues (k_rep_dots<nt> + k_rep_coef + k_rep_apply2<nt>), MI355X, rocprofv3 7.2",
       "commands": cmd, "units": units, **out["b8_twopass"],
-      "note": "1.95x the algorithmic bytes: each image's factor base is read by both passes (the counters also count Infinity-Cache hits).  The single-sweep kernel reads it once (r03_cov_apply_pmc.json) but is slower for batched launches - profiles/r03_cov_apply_single_sweep.md."}
+      "note": "1.95x the algorithmic bytes: each image's factor base is read by both passes (the counters also count Infinity-Cache hits).  The single-sweep kernel reads it once (r03_cov_apply_pmc.json) but is slower for batched launches - profiles/r02_cov_apply_single_sweep.md."}
 json.dump(b8, open("gpurun_out/r03_cov_apply_b8_pmc.json", "w"), indent=1)
 b1 = {"what": "fh_rep_apply at d=196608, m=32, float64, ONE image per launch on an exclusive context: the single-sweep kernel k_rep_fused<4>",
       "commands": cmd, "units": units, **out["b1_singlesweep"], "two_pass_for_comparison": out["b1_twopass"]}
