@@ -1470,7 +1470,9 @@ int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   const int64_t blocks = ((M + 63) / 64) * ((Cout + 63) / 64);
   const int nchunks = KH * KW * (Cin / kBK);
   int z = 1;
-  while (blocks * z < 1024 && z < 8 && nchunks / (2 * z) >= 6) z *= 2;
+  static const int target = getenv("FH_SPLITK_TARGET") ? atoi(getenv("FH_SPLITK_TARGET")) : 2048;  // 64 x 64-tile blocks x z wanted (measured: 1024 -> 2048 +9 % on the 16^2 / 32^2 grids, 4096 no better)
+  static const int zmax = getenv("FH_SPLITK_MAX") ? atoi(getenv("FH_SPLITK_MAX")) : 8;
+  while (blocks * z < target && z < zmax && nchunks / (2 * z) >= 6) z *= 2;
   return z;
 }
 
