@@ -250,6 +250,7 @@ def roofline_conv_mfma(device, iters=20):
     from free_hunch_amd import _lib
     from free_hunch_amd.unet_hip import _split3
     lib = _lib.load()
+    lib.fh_unet_set_precision(0)  # the roofline kernel is the exact-split one, whatever mode the timed run used
     N, H, W, Ci, Co, k = 8, 256, 256, 128, 128, 3
     g = torch.Generator().manual_seed(2)
     x = torch.randn(N, H, W, Ci, generator=g).to(device)
@@ -525,7 +526,7 @@ def main():
     ap.add_argument("--num-steps", type=int, default=30)
     ap.add_argument("--solver", default="heun")
     ap.add_argument("--unet-backend", default=os.environ.get("FH_UNET_BACKEND", "hip"))
-    ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "bf16x3", "bf16", "fp16"],
+    ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "fp16x3", "bf16x3", "bf16", "fp16"],
                     help="bf16: reduced-precision torso (non-parity speed mode, reported separately from the fp32 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=2, help="real UNet calls timed by the CPU-baseline leg")
@@ -585,6 +586,9 @@ def main():
                       "bf16-compute UNet convolutions (NON-PARITY mode), f32 elsewhere" if a.unet_dtype == "bf16" else
                       "UNet convolutions as 3 bf16 products of 2-plane operands (~2^-16, NON-PARITY mode), f32 elsewhere"
                       if a.unet_dtype == "bf16x3" else
+                      "f32 UNet with the 3x3 convolutions as 3 half-precision products of 2-plane operands (operands to 1 fp32 ulp, "
+                      "dropped term 2^-24 rms: fp32-convolution accuracy against float64, not bit-comparable; opt-in), f32 elsewhere"
+                      if a.unet_dtype == "fp16x3" else
                       "f32 UNet (convolutions: exact 3-way bf16 split on the bf16 MFMA, fp32 accuracy)"
                       if os.environ.get("FH_CONV_MODE", "x6") == "x6" else "f32 UNet (fp32 MFMA)") + " + f64 covariance/CG",
             "data": "synthetic",

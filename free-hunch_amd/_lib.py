@@ -40,7 +40,7 @@ class FhCovState(C.Structure):
 
 
 class FhGnEpilogue(C.Structure):
-    _fields_ = [("partial", c_dp), ("x", c_dp), ("tab", c_dp), ("mode", C.c_int32), ("act", C.c_int32)]
+    _fields_ = [("partial", c_dp), ("x", c_dp), ("tab", c_dp), ("mode", C.c_int32), ("act", C.c_int32), ("in_amax", c_dp)]
 
 
 class FhCgInfo(C.Structure):
@@ -92,9 +92,10 @@ _SIGS = {
     "fh_groupnorm_bwd_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_groupnorm_bwd_apply": ([c_dp] * 8 + [C.c_int, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_groupnorm_bwd_sums": ([c_dp] * 7 + [C.c_int, c_dp, c_dp] + [C.c_int] * 4 + [C.c_void_p], C.c_int),
-    "fh_groupnorm_bwd_apply_ex": ([c_dp] * 8 + [C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
+    "fh_groupnorm_bwd_apply_ex": ([c_dp] * 8 + [C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [c_dp, C.c_void_p], C.c_int),
     "fh_conv2d_splitk": ([C.c_int] * 7, C.c_int),
     "fh_unet_set_precision": ([C.c_int], C.c_int),
+    "fh_absmax_f32": ([c_dp, C.c_int64, c_dp, C.c_void_p], C.c_int),
     "fh_groupnorm_table": ([c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_conv2d_x6_norm_supported": ([C.c_int] * 5, C.c_int),
     "fh_conv2d_x6_norm_nhwc": ([c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),

@@ -205,6 +205,10 @@ struct ConvArgsX {
   const float* gn_x;    // mode 1: forward input of the GroupNorm whose backward consumes this output
   const float* gn_tab;  // mode 1: [N][5][Cout]  A, Bc, mean, rstd, gamma (1 + scale)
   int gn_mode, gn_act, gn_chunks;
+  // half-split mode (NP = 2 on the f16 MFMA): the activation operand is staged as x * 2^k; k from the tensor's largest
+  // magnitude (in_amax, device) or, for the fused-GroupNorm input, the fixed in_scale
+  const float* in_amax;
+  float in_scale;
 };
 
 // SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions): the fused-input convolution
@@ -286,6 +290,42 @@ __device__ __forceinline__ float16_t mfma16(bf16x8_t a, bf16x8_t b, float16_t c)
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// Half-split mode (NP = 2 with F16): x 2^k = h + m with h = rn_half(x 2^k), m = rn_half(x 2^k - h): h + m carries x to
+// <= 2^-23 relative (the residual has at most 13 significant bits, the half keeps 11 of them: at most one unit of the
+// fp32 last place is lost, and nothing for three operands out of four) as long as m stays a normal half, i.e. for
+// |x| 2^k >= 2^-3; smaller elements keep an absolute error of 2^-25 / 2^k.  The three products h h' + h m' + m h' drop
+// m m' (<= 2^-22 |x x'|, 2^-24 rms): in total below the rounding noise of the fp32 accumulation that every fp32
+// convolution carries (sqrt(K) 2^-25 of a term at K = 9 Cin), measured in tests/test_hip_unet.py against float64.
+struct SplitScale {
+  float in, inv_in, winv;
+};
+template <int NP, bool F16>
+__device__ __forceinline__ SplitScale split_scale(const ConvArgsX& a, int64_t wplane) {
+  SplitScale s{1.f, 1.f, 1.f};
+  if (F16 && NP == 2) {
+    s.winv = *reinterpret_cast<const float*>(a.wx + 2 * wplane);  // 1 / (power-of-two scale of the weight planes), behind them
+    if (a.in_amax != nullptr) {  // largest magnitude (the max over the FH_AMAX_SLOTS partial maxima) -> [2^11, 2^12)
+      unsigned mb = 0u;
+#pragma unroll
+      for (int q = 0; q < FH_AMAX_SLOTS; ++q) mb = max(mb, __float_as_uint(a.in_amax[q]));
+      int e = (int)((mb >> 23) & 255u) - 127;
+      e = e < -110 ? -110 : (e > 126 ? 126 : e);
+      s.in = __uint_as_float((unsigned)(127 + 11 - e) << 23);
+      s.inv_in = __uint_as_float((unsigned)(127 - 11 + e) << 23);
+    } else {
+      s.in = a.in_scale;
+      s.inv_in = 1.f / a.in_scale;  // (a power of two)
+    }
+  }
+  return s;
+}
+__device__ __forceinline__ void split_half2(float xs, __bf16& h, __bf16& m) {
+  xs = fminf(fmaxf(xs, -65504.f), 65504.f);  // saturate instead of overflowing (fixed-scale inputs only)
+  const _Float16 hh = (_Float16)xs;
+  h = __builtin_bit_cast(__bf16, hh);
+  m = half_bits(xs - (float)hh);
+}
+
 // NP = 3: the exact split above (six products).  NP = 2: the two leading planes, three products (h h' + h m' + m h'):
 // operands carried to 2^-17, product terms below 2^-16 dropped - between TF32 (2^-11, the default convolution arithmetic of
 // the reference's CUDA path) and fp32.  NP = 1: plain bf16 compute - operands rounded to bf16 (plane 0 = rn(x)),
@@ -338,6 +378,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
   }
   // weights: wx [3][taps][Cin/32][Cout][32] - the B tile of one plane is BN contiguous 64-byte rows
   const int64_t wplane = (int64_t)taps * cpt * a.Cout * kBK;
+  const SplitScale ssc = split_scale<NP, F16>(a, wplane);
   int b_pl[IB], b_row[IB];
   bool b_ok[IB];
   const int b_part = (tid & 3) * 8;
@@ -382,8 +423,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
       for (int q = 0; q < 4; ++q) {
         const float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
         __bf16 h, m, l;
-        split3(x, h, m, l);
-        if (F16) h = half_bits(x);
+        if (F16 && NP == 2) {
+          split_half2(x * ssc.in, h, m);
+          l = m;
+        } else {
+          split3(x, h, m, l);
+          if (F16) h = half_bits(x);
+        }
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
@@ -426,8 +472,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
         }
         if (NP >= 2) {  // m h', h m'
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
+          t = mfma16<F16>(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t);
+          t = mfma16<F16>(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t);
         }
         t = mfma16<F16>(af[0][i], bfr[0][j], t);  // h h'
         acc[i][j] = t;
@@ -471,7 +517,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < M) {
-          float v = acc[i][j][r] + bv;
+          float v = acc[i][j][r];
+          if (F16 && NP == 2) v = v * ssc.inv_in * ssc.winv;
+          v += bv;
           if (a.res != nullptr && a.ksplit == 1) v += a.res[row * a.Cout + co];
           dst[row * a.Cout + co] = v;
           if (gn) gn_accum(a, gsum[j], v, row, co, tb);
@@ -549,6 +597,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
     if (idx >= AR * 8) a_row[e] = -1;
   }
   const int64_t wplane = (int64_t)9 * cpt * a.Cout * kBK;
+  const SplitScale ssc = split_scale<NP, F16>(a, wplane);
   int b_pl[IB], b_row[IB];
   bool b_ok[IB];
   const int b_part = (tid & 3) * 8;
@@ -623,8 +672,13 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
           x = ra_ok[e] ? (a.act ? silu_f(t) : t) : 0.f;
         }
         __bf16 h, m, l;
-        split3(x, h, m, l);
-        if (F16) h = half_bits(x);
+        if (F16 && NP == 2) {
+          split_half2(x * ssc.in, h, m);
+          l = m;
+        } else {
+          split3(x, h, m, l);
+          if (F16) h = half_bits(x);
+        }
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
       *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
@@ -674,8 +728,8 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
             t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
           }
           if (NP >= 2) {  // m h', h m'
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t, 0, 0, 0);
+            t = mfma16<F16>(af[NP >= 2 ? 1 : 0][i], bfr[0][j], t);
+            t = mfma16<F16>(af[0][i], bfr[NP >= 2 ? 1 : 0][j], t);
           }
           t = mfma16<F16>(af[0][i], bfr[0][j], t);
           acc[i][j] = t;
@@ -750,7 +804,9 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < M) {
-          float v = acc[i][j][r] + bv;
+          float v = acc[i][j][r];
+          if (F16 && NP == 2) v = v * ssc.inv_in * ssc.winv;
+          v += bv;
           if (a.res != nullptr) v += a.res[row * a.Cout + co];
           a.out[row * a.Cout + co] = v;
           if (gn) gn_accum(a, gsum[j], v, row, co, tb);
@@ -989,6 +1045,25 @@ __global__ __launch_bounds__(256) void k_conv_thin(const float* __restrict__ in,
 }
 
 // split-K epilogue: out = sum_z ws[z] + bias (+ res), fixed summation order
+// max |x| of a tensor: non-negative floats order like their bit patterns, so the block maxima meet in one atomicMax on the
+// uint image (order-independent, hence deterministic).  A NaN anywhere wins (its pattern is above +inf's).
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = max(max(m, __float_as_uint(fabsf(v.x))), max(__float_as_uint(fabsf(v.y)), max(__float_as_uint(fabsf(v.z)), __float_as_uint(fabsf(v.w)))));
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = max(m, __float_as_uint(fabsf(x[i])));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // (same-address atomics serialise in L2: the blocks spread over FH_AMAX_SLOTS slots, the reader takes their max)
+  if (threadIdx.x == 0) atomicMax(out + (blockIdx.x % FH_AMAX_SLOTS), max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+}
+
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
                                                        const float* __restrict__ res, float* __restrict__ out,
                                                        int64_t total, int Cout, int ksplit) {
@@ -1237,15 +1312,19 @@ __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, 
                                                    int accumulate, int nchunks, int kGnChunk,
                                                    const float* __restrict__ acc_src = nullptr,
                                                    const float* __restrict__ add2 = nullptr, float* __restrict__ out2 = nullptr,
-                                                   int csplit = 0) {
+                                                   int csplit = 0, unsigned* __restrict__ amax = nullptr) {
+  // amax (backward, optional): [2][FH_AMAX_SLOTS] uint images of max |out|, max |out2|, folded in with atomicMax (the caller zeroes them):
+  // the magnitude the half-split input-gradient convolution that consumes the tensor scales it by (fh_absmax_f32's result)
+  unsigned mx0 = 0u, mx1 = 0u;
   const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
   const int cg = C / 32, c4n = C / 4;
   const int p0 = chunk * kGnChunk;
   const int p1 = p0 + kGnChunk < P ? p0 + kGnChunk : P;
   const int lanes_p = c4n >= 256 ? 1 : 256 / c4n;
   const int active = c4n >= 256 ? 256 : lanes_p * c4n;
-  if ((int)threadIdx.x >= active) return;
-  for (int c4 = threadIdx.x % (c4n < 256 ? c4n : 256); c4 < c4n; c4 += 256) {
+  const bool live = (int)threadIdx.x < active;
+  if (!live && !(BWD && amax != nullptr)) return;
+  for (int c4 = threadIdx.x % (c4n < 256 ? c4n : 256); live && c4 < c4n; c4 += 256) {
     const int psub = c4n >= 256 ? 0 : threadIdx.x / c4n;
     float A[4], Bc[4], mean[4], rstd[4], gsc[4], sa[4], sb[4];
 #pragma unroll
@@ -1310,6 +1389,14 @@ __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, 
             o[e] = ((accumulate || add2 != nullptr) ? os[e] : 0.f) + rstd[e] * (g - sa[e] - xh * sb[e]);
           }
         }
+        if (BWD && amax != nullptr) {
+          const unsigned m4 = max(max(__float_as_uint(fabsf(o[0])), __float_as_uint(fabsf(o[1]))),
+                                  max(__float_as_uint(fabsf(o[2])), __float_as_uint(fabsf(o[3]))));
+          if (out2 != nullptr && 4 * c4 >= csplit)
+            mx1 = max(mx1, m4);
+          else
+            mx0 = max(mx0, m4);
+        }
         if (BWD && out2 != nullptr) {
           const int64_t pix = (int64_t)n * P + pb + u * lanes_p;
           float* dst = 4 * c4 < csplit ? out + pix * csplit + 4 * c4 : out2 + pix * (C - csplit) + (4 * c4 - csplit);
@@ -1317,6 +1404,22 @@ __global__ __launch_bounds__(256) void k_gn_stream(const float* __restrict__ x, 
         } else
         *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
       }
+    }
+  }
+  if (BWD && amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx0 = max(mx0, (unsigned)__shfl_xor((int)mx0, o, 64));
+      mx1 = max(mx1, (unsigned)__shfl_xor((int)mx1, o, 64));
+    }
+    __shared__ unsigned sm[8];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx0, sm[4 + (threadIdx.x >> 6)] = mx1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx0 = max(max(sm[0], sm[1]), max(sm[2], sm[3])), mx1 = max(max(sm[4], sm[5]), max(sm[6], sm[7]));
+      const int slot = blockIdx.x % FH_AMAX_SLOTS;
+      if (mx0) atomicMax(amax + slot, mx0);
+      if (mx1) atomicMax(amax + FH_AMAX_SLOTS + slot, mx1);
     }
   }
 }
@@ -1445,8 +1548,10 @@ extern "C" {
 // Precision of the bf16-MFMA convolution kernels: 3 = exact 3-way split (fp32 accuracy, default), 1 = plain bf16 compute
 // (operands rounded to bf16, one product, fp32 accumulation) - the reduced-precision UNet mode, the counterpart of the
 // reference's use_fp16 torso (training/openai_fp16_util.py:15-32).  Process-wide: set before a forward / VJP.
-static int g_conv_np = 3;
-#define X6_DISPATCH(K1, K2, K3, K16, ...)             \
+// Mode 4 (half-split, 32): two half-precision planes per operand, three products on the f16 MFMA (see split_scale above):
+// the host picks it per launch, so the switch is per host thread (the lock-step groups of a process launch concurrently).
+static thread_local int g_conv_np = 3;
+#define X6_DISPATCH(K1, K2, K3, K16, K32, ...)        \
   do {                                               \
     if (g_conv_np == 1)                              \
       hipLaunchKernelGGL(K1, __VA_ARGS__);           \
@@ -1454,13 +1559,29 @@ static int g_conv_np = 3;
       hipLaunchKernelGGL(K2, __VA_ARGS__);           \
     else if (g_conv_np == 16)                        \
       hipLaunchKernelGGL(K16, __VA_ARGS__);          \
+    else if (g_conv_np == 32)                        \
+      hipLaunchKernelGGL(K32, __VA_ARGS__);          \
     else                                             \
       hipLaunchKernelGGL(K3, __VA_ARGS__);           \
   } while (0)
 
 int fh_unet_set_precision(int mode) {
-  if (mode < 0 || mode > 3) return FH_EINVAL;
-  g_conv_np = mode == 0 ? 3 : (mode == 1 ? 1 : (mode == 2 ? 2 : 16));  // 16: one half-precision plane on the f16 MFMA
+  if (mode < 0 || mode > 4) return FH_EINVAL;
+  // 16: one half-precision plane on the f16 MFMA; 32: two half-precision planes, three products
+  g_conv_np = mode == 0 ? 3 : (mode == 1 ? 1 : (mode == 2 ? 2 : (mode == 3 ? 16 : 32)));
+  return 0;
+}
+
+int fh_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (!out || n < 0 || (n > 0 && !x) || ((uintptr_t)x & 15)) return FH_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  FH_CHECK(hipMemsetAsync(out, 0, FH_AMAX_SLOTS * sizeof(float), st));
+  if (n > 0) {
+    const int64_t want = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want))), dim3(256), 0, st, x, n,
+                       reinterpret_cast<unsigned*>(out));
+  }
+  FH_LAUNCH_CHECK();
   return 0;
 }
 
@@ -1553,6 +1674,9 @@ int fh_conv2d_x6_gn_chunks(int ksplit, int N, int H, int W, int Cin, int Cout, i
 
 static int set_gn(ConvArgsX& a, const fh_gn_epilogue* epi, int chunks) {
   a.gn_partial = nullptr, a.gn_x = nullptr, a.gn_tab = nullptr, a.gn_mode = a.gn_act = a.gn_chunks = 0;
+  a.in_amax = epi != nullptr ? epi->in_amax : nullptr, a.in_scale = 1.f;
+  if (g_conv_np == 32 && a.ab == nullptr && a.in_amax == nullptr) return FH_EINVAL;  // half-split of a raw tensor needs its magnitude
+  if (a.ab != nullptr) a.in_amax = nullptr, a.in_scale = 16.f;  // GroupNorm(+SiLU) output: O(1) by construction
   if (epi == nullptr || epi->partial == nullptr) return 0;
   if (chunks <= 0 || epi->mode < 0 || epi->mode > 1 || (epi->mode == 1 && (!epi->x || !epi->tab))) return FH_EINVAL;
   a.gn_partial = epi->partial, a.gn_x = epi->x, a.gn_tab = epi->tab;
@@ -1590,32 +1714,32 @@ static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, co
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
     static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;  // weight tile by LDS-DMA (default; 0 = register staging, the A/B switch)
     if (big && glds && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), (k_conv_x6r<256, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), (k_conv_x6r<256, false, 256, 1, true, true>), (k_conv_x6r<256, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), (k_conv_x6r<128, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), (k_conv_x6r<128, false, 256, 1, true, true>), (k_conv_x6r<128, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), (k_conv_x6r<64, false, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), (k_conv_x6r<64, false, 256, 1, true, true>), (k_conv_x6r<64, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), (k_conv_x6r<256, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), (k_conv_x6r<256, false, 256, 1, false, true>), (k_conv_x6r<256, false, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), (k_conv_x6r<128, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1>), (k_conv_x6r<128, false, 256, 2>), (k_conv_x6r<128, false, 256, 3>), (k_conv_x6r<128, false, 256, 1, false, true>), (k_conv_x6r<128, false, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 2>), (k_conv_x6r<64, false, 256, 3>), (k_conv_x6r<64, false, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1>), (k_conv_x6r<64, false, 256, 2>), (k_conv_x6r<64, false, 256, 3>), (k_conv_x6r<64, false, 256, 1, false, true>), (k_conv_x6r<64, false, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
     else if (r3 && W % 128 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 2>), (k_conv_x6r<128, false, 128, 3>), (k_conv_x6r<128, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 128, 1>), (k_conv_x6r<128, false, 128, 2>), (k_conv_x6r<128, false, 128, 3>), (k_conv_x6r<128, false, 128, 1, false, true>), (k_conv_x6r<128, false, 128, 2, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 64 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 2>), (k_conv_x6r<64, false, 128, 3>), (k_conv_x6r<64, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 128, 1>), (k_conv_x6r<64, false, 128, 2>), (k_conv_x6r<64, false, 128, 3>), (k_conv_x6r<64, false, 128, 1, false, true>), (k_conv_x6r<64, false, 128, 2, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else if (r3 && W == 32 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 2>), (k_conv_x6r<32, false, 128, 3>), (k_conv_x6r<32, false, 128, 1, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<32, false, 128, 1>), (k_conv_x6r<32, false, 128, 2>), (k_conv_x6r<32, false, 128, 3>), (k_conv_x6r<32, false, 128, 1, false, true>), (k_conv_x6r<32, false, 128, 2, false, true>), dim3((unsigned)(M / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
     else
-      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
+      X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), (k_conv_x6<2, 1, 2, 4, 4, 2, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, 1), dim3(512), 0, st, a);
   } else if (ksplit > 1 && Cout > 64 && b128 * ksplit >= 256 && !getenv("FH_X6_NOBIGSPLIT")) {
     // small grids: 128 x 128 tiles (21 flop per byte pulled from L2 instead of 12.8) once split-K still fills the chip
-    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6<2, 1, 2, 4, 4, 1>), (k_conv_x6<2, 1, 2, 4, 4, 2>), (k_conv_x6<2, 1, 2, 4, 4, 3>), (k_conv_x6<2, 1, 2, 4, 4, 1, true>), (k_conv_x6<2, 1, 2, 4, 4, 2, true>), dim3((unsigned)((M + 127) / 128), (Cout + 127) / 128, Z), dim3(512), 0, st, a);
   } else if (ksplit == 1 && Cout > 64 && ((M + 63) / 64) * ((Cout + 127) / 128) >= 256) {
-    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 2>), (k_conv_x6<1, 2, 2, 2, 2, 3>), (k_conv_x6<1, 2, 2, 2, 2, 1, true>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 2, 2, 2, 2, 1>), (k_conv_x6<1, 2, 2, 2, 2, 2>), (k_conv_x6<1, 2, 2, 2, 2, 3>), (k_conv_x6<1, 2, 2, 2, 2, 1, true>), (k_conv_x6<1, 2, 2, 2, 2, 2, true>), dim3((unsigned)((M + 63) / 64), (Cout + 127) / 128, 1), dim3(256), 0, st, a);
   } else {
-    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 2>), (k_conv_x6<1, 1, 2, 2, 2, 3>), (k_conv_x6<1, 1, 2, 2, 2, 1, true>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
+    X6_DISPATCH((k_conv_x6<1, 1, 2, 2, 2, 1>), (k_conv_x6<1, 1, 2, 2, 2, 2>), (k_conv_x6<1, 1, 2, 2, 2, 3>), (k_conv_x6<1, 1, 2, 2, 2, 1, true>), (k_conv_x6<1, 1, 2, 2, 2, 2, true>), dim3((unsigned)((M + 63) / 64), (Cout + 63) / 64, Z), dim3(256), 0, st, a);
   }
   if (ksplit > 1) {
     const int64_t total = M * Cout;
@@ -1698,23 +1822,23 @@ static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, 
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
   static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;
   if (big && glds && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), (k_conv_x6r<256, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), (k_conv_x6r<256, true, 256, 1, true, true>), (k_conv_x6r<256, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), (k_conv_x6r<128, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), (k_conv_x6r<128, true, 256, 1, true, true>), (k_conv_x6r<128, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), (k_conv_x6r<64, true, 256, 1, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), (k_conv_x6r<64, true, 256, 1, true, true>), (k_conv_x6r<64, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), (k_conv_x6r<256, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), (k_conv_x6r<256, true, 256, 1, false, true>), (k_conv_x6r<256, true, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), (k_conv_x6r<128, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1>), (k_conv_x6r<128, true, 256, 2>), (k_conv_x6r<128, true, 256, 3>), (k_conv_x6r<128, true, 256, 1, false, true>), (k_conv_x6r<128, true, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 2>), (k_conv_x6r<64, true, 256, 3>), (k_conv_x6r<64, true, 256, 1, false, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1>), (k_conv_x6r<64, true, 256, 2>), (k_conv_x6r<64, true, 256, 3>), (k_conv_x6r<64, true, 256, 1, false, true>), (k_conv_x6r<64, true, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
   else if (W % 128 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 2>), (k_conv_x6r<128, true, 128, 3>), (k_conv_x6r<128, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 128, 1>), (k_conv_x6r<128, true, 128, 2>), (k_conv_x6r<128, true, 128, 3>), (k_conv_x6r<128, true, 128, 1, false, true>), (k_conv_x6r<128, true, 128, 2, false, true>), grid, dim3(512), 0, st, a);
   else if (W == 64)
-    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 2>), (k_conv_x6r<64, true, 128, 3>), (k_conv_x6r<64, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 128, 1>), (k_conv_x6r<64, true, 128, 2>), (k_conv_x6r<64, true, 128, 3>), (k_conv_x6r<64, true, 128, 1, false, true>), (k_conv_x6r<64, true, 128, 2, false, true>), grid, dim3(512), 0, st, a);
   else
-    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 2>), (k_conv_x6r<32, true, 128, 3>), (k_conv_x6r<32, true, 128, 1, false, true>), grid, dim3(512), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<32, true, 128, 1>), (k_conv_x6r<32, true, 128, 2>), (k_conv_x6r<32, true, 128, 3>), (k_conv_x6r<32, true, 128, 1, false, true>), (k_conv_x6r<32, true, 128, 2, false, true>), grid, dim3(512), 0, st, a);
   FH_LAUNCH_CHECK();
   return 0;
 }
@@ -1893,7 +2017,8 @@ int fh_groupnorm_bwd_sums(const float* x, const float* dy, const float* stats, c
 // second addend) and the split destination (dx: [.., csplit], dx2: [.., C - csplit]); any of them may be null / 0
 int fh_groupnorm_bwd_apply_ex(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
                               const float* beta, const float* scale, const float* shift, int ss_stride, const float* acc_src,
-                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, void* stream) {
+                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, float* amax2,
+                              void* stream) {
   if (!x || !dy || !stats || !sums || !gamma || !beta || !dx || C % 32 != 0) return FH_EINVAL;
   if (dx2 != nullptr && (csplit <= 0 || csplit >= C || csplit % 4 != 0)) return FH_EINVAL;
   if (dx2 == nullptr && acc_src != nullptr && acc_src != dx) {
@@ -1903,7 +2028,7 @@ int fh_groupnorm_bwd_apply_ex(const float* x, const float* dy, const float* stat
   const int nchunks = (P + kGnChunk - 1) / kGnChunk;
   hipLaunchKernelGGL(k_gn_stream<1>, dim3(N * nchunks), dim3(256), 0, (hipStream_t)stream, x, dy, stats, sums, gamma, beta,
                      scale, shift, ss_stride, dx, P, C, act, acc_src != nullptr ? 1 : 0, nchunks, kGnChunk, acc_src, add2, dx2,
-                     csplit);
+                     csplit, reinterpret_cast<unsigned*>(amax2));
   FH_LAUNCH_CHECK();
   return 0;
 }

@@ -65,6 +65,25 @@ def _half_plane(w):
     return w.to(torch.float16).view(torch.int16).reshape(1, rows, taps, k // _K, _K).permute(0, 2, 3, 1, 4).contiguous()
 
 
+_AMAX_SLOTS = 16  # FH_AMAX_SLOTS of include/fh_hip.h
+
+
+def _half_split_planes(w):
+    """fp32 [rows][taps][K] -> the weight operand of the half-split mode (fh_unet_set_precision(4)): int16 bit patterns of
+    h = rn_half(w 2^k), m = rn_half(w 2^k - h) as [2 planes][taps][K/32][rows][32], followed by ONE float32 = 2^-k (two int16
+    slots).  k puts the largest |w| into [2^12, 2^13): every weight above 2^-16 of the largest keeps h + m == w 2^k to one
+    fp32 ulp (m stays a normal half)."""
+    rows, taps, k = w.shape
+    amax = float(w.abs().max())
+    kk = 12 - math.floor(math.log2(amax)) if amax > 0 else 0
+    ws = w * (2.0 ** kk)
+    h = ws.to(torch.float16)
+    m = (ws - h.float()).to(torch.float16)
+    planes = torch.stack([h, m]).view(torch.int16).reshape(2, rows, taps, k // _K, _K).permute(0, 2, 3, 1, 4).contiguous()
+    tail = torch.tensor([2.0 ** -kk], dtype=torch.float32, device=w.device).view(torch.int16)
+    return torch.cat([planes.flatten(), tail])
+
+
 def _use_x6(N, H, W, rows_out):
     """Measured on MI355X (profiles/tools/bench_x6.py): the split-bf16 kernel is 1.2-1.4x the fp32-MFMA kernel (1.05-1.1x the
     Winograd one) on the large layers and, with the same deterministic split-K, 1.0-1.2x on the 8 x 8 ... 32 x 32 grids;
@@ -95,12 +114,18 @@ class _Conv:
             self.wu_f = _wino(wf.reshape(co, 3, 3, self.ci_p))
             self.wu_d = _wino(wd.reshape(ci, 3, 3, self.co_p))
         self.wh_f = self.wh_d = None  # half-precision planes, built when the fp16 mode is first used
+        self.ws_f = self.ws_d = None  # half-split planes (precision mode 4), built on first use
         if CONV_MODE == "x6":  # exact bf16 split of both copies (6 bytes per weight)
             self.wx_f, self.wx_d = _split3(self.wf), _split3(self.wd)
 
-    def planes(self, fwd, fp16):
-        """the weight operand of the split-bf16 kernels: the three bf16 planes, or the half-precision plane (fp16 mode)"""
-        if not fp16:
+    def planes(self, fwd, mode):
+        """the weight operand of the split-bf16 kernels for fh_unet_set_precision(mode): the three bf16 planes (modes 0-2),
+        the half-precision plane (3) or the two half-split planes + scale (4)"""
+        if mode == 4:
+            if self.ws_f is None:
+                self.ws_f, self.ws_d = _half_split_planes(self.wf), _half_split_planes(self.wd)
+            return self.ws_f if fwd else self.ws_d
+        if mode != 3:
             return self.wx_f if fwd else self.wx_d
         if self.wh_f is None:
             self.wh_f, self.wh_d = _half_plane(self.wf), _half_plane(self.wd)
@@ -122,6 +147,34 @@ class HipOps:
         self._tls = threading.local()  # emb_key: the timestep tuple of the call running on THIS host thread
 
     # ---------------------------------------------------------------- kernel wrappers
+    def _launch_mode(self, c, stride=1, x=None):
+        """fh_unet_set_precision code of ONE split-kernel launch.  The half-split mode (4) covers the 3 x 3 / stride 1
+        layers (97 % of the matrix work) and the 1 x 1 ones whose input `x` arrives with its magnitude (`_fh_amax`, left by the
+        GroupNorm-backward pass that wrote it); other 1 x 1 and strided convolutions keep the exact bf16 split, where the
+        extra pass for the input's magnitude would cost what the cheaper products save."""
+        if self.bf16 != 4:
+            return self.bf16
+        m = 4 if (stride == 1 and ((c.kh == 3 and c.kw == 3) or getattr(x, "_fh_amax", None) is not None)) else 0
+        self.lib.fh_unet_set_precision(m)  # (per host thread)
+        return m
+
+    def _amax_slot(self):
+        """[2][FH_AMAX_SLOTS] zeroed device floats out of a pool that one fill serves for a whole backward pass"""
+        pool = getattr(self._tls, "amax_pool", None)
+        if pool is None or pool[1] >= pool[0].shape[0]:
+            dev = self.P[next(iter(self.P))].device
+            pool = self._tls.amax_pool = [torch.zeros(256, 2, _AMAX_SLOTS, dtype=torch.float32, device=dev), 0]
+        pool[1] += 1
+        return pool[0][pool[1] - 1]
+
+    def _amax(self, x):
+        pre = getattr(x, "_fh_amax", None)  # left by the GroupNorm-backward pass that wrote x
+        if pre is not None:
+            return pre
+        out = torch.empty(_AMAX_SLOTS, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.fh_absmax_f32(x.data_ptr(), x.numel(), out.data_ptr(), _lib.stream()), "fh_absmax_f32")
+        return out
+
     def _conv(self, name, x, res=None, bias_override=None, stride=1):
         c = self.conv[name]
         N, H, W, Ci = x.shape
@@ -133,8 +186,8 @@ class HipOps:
             out = torch.empty(N, Ho, Wo, c.co, dtype=torch.float32, device=x.device)
             ks = self.lib.fh_conv2d_splitk(N, Ho, Wo, Ci, c.co, c.kh, c.kw)
             ws = torch.empty(ks, N * Ho * Wo, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
-            fn, wgt = ((self.lib.fh_conv2d_x6_nhwc, c.planes(True, self.bf16 == 3)) if c.wx_f is not None and _use_x6(N, Ho, Wo, c.co)
-                       else (self.lib.fh_conv2d_nhwc, c.wf))
+            fn, wgt = ((self.lib.fh_conv2d_x6_nhwc, c.planes(True, self._launch_mode(c, stride)))
+                       if c.wx_f is not None and _use_x6(N, Ho, Wo, c.co) else (self.lib.fh_conv2d_nhwc, c.wf))
             _lib.check(fn(x.data_ptr(), wgt.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(),
                           out.data_ptr(), None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh, c.kw, pad,
                           stride, _lib.stream()), "fh_conv2d(stride)")
@@ -153,8 +206,10 @@ class HipOps:
         ws = torch.empty(ks, N * H * W, c.co, dtype=torch.float32, device=x.device) if ks > 1 else None
         if c.wx_f is not None and _use_x6(N, H, W, c.co):
             # group-sum epilogue: the statistics of a GroupNorm applied to this output come out of the convolution itself
-            epi, keep = self._epilogue(ks, N, H, W, Ci, c.co, c.kh, c.kw, pad, 0)
-            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), c.planes(True, self.bf16 == 3).data_ptr(), b.data_ptr(),
+            m = self._launch_mode(c)
+            amax = self._amax(x) if m == 4 else None
+            epi, keep = self._epilogue(ks, N, H, W, Ci, c.co, c.kh, c.kw, pad, 0, amax=amax)
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(x.data_ptr(), c.planes(True, m).data_ptr(), b.data_ptr(),
                                                      None if res is None else res.data_ptr(), out.data_ptr(),
                                                      None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, c.co, c.kh,
                                                      c.kw, pad, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc")
@@ -190,10 +245,11 @@ class HipOps:
         ks = self.lib.fh_conv2d_splitk(N, H, W, c.co_p, c.ci, c.kh, c.kw)
         ws = torch.empty(ks, N * H * W, c.ci, dtype=torch.float32, device=g.device) if ks > 1 else None
         if c.wx_d is not None and _use_x6(N, H, W, c.ci):
-            epi, keep = (None, None)
-            if gn is not None and gn[1].shape == out.shape:
-                epi, keep = self._epilogue(ks, N, H, W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1, gn)
-            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(g.data_ptr(), c.planes(False, self.bf16 == 3).data_ptr(), None,
+            m = self._launch_mode(c, 1, g)
+            amax = self._amax(g) if m == 4 else None
+            epi, keep = self._epilogue(ks, N, H, W, c.co_p, c.ci, c.kh, c.kw, c.kh // 2, 1,
+                                       gn if gn is not None and gn[1].shape == out.shape else None, amax=amax)
+            _lib.check(self.lib.fh_conv2d_x6_nhwc_gn(g.data_ptr(), c.planes(False, m).data_ptr(), None,
                                                      None if res is None else res.data_ptr(), out.data_ptr(),
                                                      None if ws is None else ws.data_ptr(), ks, N, H, W, c.co_p, c.ci, c.kh,
                                                      c.kw, c.kh // 2, 1, epi, _lib.stream()), "fh_conv2d_x6_nhwc(dgrad)")
@@ -210,18 +266,25 @@ class HipOps:
                                            c.ci, c.kh, c.kw, c.kh // 2, 1, _lib.stream()), "fh_conv2d_nhwc(dgrad)")
         return out
 
-    def _epilogue(self, ks, N, H, W, Ci, Co, kh, kw, pad, mode, gn=None):
+    def _epilogue(self, ks, N, H, W, Ci, Co, kh, kw, pad, mode, gn=None, amax=None):
         """fh_gn_epilogue for the split-bf16 convolution launch of this layer, or (None, None) where the launch has none
-        (split-K, thin output, ...).  mode 0: statistics of the output; mode 1: backward sums of the GroupNorm `gn`."""
-        if os.environ.get("FH_GN_EPILOGUE", "1") == "0" or Co % 32 != 0:
-            return None, None
-        chunks = self.lib.fh_conv2d_x6_gn_chunks(ks, N, H, W, Ci, Co, kh, kw, pad, 1)
+        (split-K, thin output, ...).  mode 0: statistics of the output; mode 1: backward sums of the GroupNorm `gn` (None =
+        no group sums wanted).  `amax` (half-split mode): the input's magnitude rides in the same struct; the second
+        return value is None when the launch leaves no group partials."""
+        chunks = 0
+        if os.environ.get("FH_GN_EPILOGUE", "1") != "0" and Co % 32 == 0 and not (mode == 1 and gn is None):
+            chunks = self.lib.fh_conv2d_x6_gn_chunks(ks, N, H, W, Ci, Co, kh, kw, pad, 1)
         if chunks <= 0:
-            return None, None
+            if amax is None:
+                return None, None
+            e = _lib.FhGnEpilogue()
+            e.partial, e.in_amax = None, amax.data_ptr()
+            return C.byref(e), None
         dev = self.P[next(iter(self.P))].device
         partial = torch.empty(N * chunks * 64, dtype=torch.float64, device=dev)
         e = _lib.FhGnEpilogue()
         e.partial, e.mode, e.act = partial.data_ptr(), mode, 0
+        e.in_amax = None if amax is None else amax.data_ptr()
         keep = [partial, chunks]
         if mode == 1:
             gn_name, x, stats, act, scale, shift = gn
@@ -285,7 +348,7 @@ class HipOps:
             out = torch.empty(N, H, W, c.co, dtype=torch.float32, device=x.device)
             epi, keep = self._epilogue(1, N, H, W, Ci, c.co, 3, 3, 1, 0)
             _lib.check(self.lib.fh_conv2d_x6_norm_nhwc_gn(x.data_ptr(), table.data_ptr(), int(act),
-                                                          c.planes(True, self.bf16 == 3).data_ptr(),
+                                                          c.planes(True, self._launch_mode(c)).data_ptr(),
                                                           c.b.data_ptr(), None if res is None else res.data_ptr(),
                                                           out.data_ptr(), N, H, W, Ci, c.co, epi, _lib.stream()),
                        "fh_conv2d_x6_norm_nhwc")
@@ -314,10 +377,16 @@ class HipOps:
             dx2 = torch.empty(N, H, W, split[1], dtype=torch.float32, device=x.device)
         else:
             dx, dx2 = (acc if acc is not None else torch.empty_like(x)), None
+        amax = self._amax_slot() if self.bf16 == 4 else None  # the magnitudes of dx, dx2 for the half-split dgrad that follows
         _lib.check(self.lib.fh_groupnorm_bwd_apply_ex(
             x.data_ptr(), dy.data_ptr(), stats.data_ptr(), sums.data_ptr(), *gp, None if acc is None else acc.data_ptr(),
             None if add2 is None else add2.data_ptr(), dx.data_ptr(), None if dx2 is None else dx2.data_ptr(),
-            0 if split is None else split[0], N, H * W, C_, int(act), _lib.stream()), "gn_bwd_apply")
+            0 if split is None else split[0], N, H * W, C_, int(act), None if amax is None else amax.data_ptr(),
+            _lib.stream()), "gn_bwd_apply")
+        if amax is not None:
+            dx._fh_amax = amax[0]
+            if dx2 is not None:
+                dx2._fh_amax = amax[1]
         return dx if split is None else (dx, dx2)
 
     def _resample(self, x, mode):
@@ -502,6 +571,7 @@ class HipOps:
         N, Co, H, W = g_nchw.shape
         st = _lib.stream()
         self.lib.fh_unet_set_precision(int(self.bf16))
+        self._tls.amax_pool = None  # (slots are written by atomicMax: a fresh zeroed pool per pass)
         cp = self.conv["out.2"].co_p
         g = torch.empty(N, H, W, cp, dtype=torch.float32, device=g_nchw.device)
         _lib.check(self.lib.fh_layout_nchw_nhwc(g_nchw.contiguous().data_ptr(), g.data_ptr(), N, Co, H * W, cp, 1, st),

@@ -285,8 +285,19 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
  * operands, three products (relative error ~ 2^-16: between TF32, the default convolution arithmetic of the reference's
  * CUDA path, and fp32) - half the matrix work of mode 0; 3 = the reference's fp16 torso arithmetic: operands rounded to IEEE
  * half precision, one product on v_mfma_f32_32x32x16_f16, fp32 accumulation (the weight operand is then ONE plane of
- * half-precision bit patterns in the same [taps][Cin/32][Cout][32] layout).  Process-wide. */
+ * half-precision bit patterns in the same [taps][Cin/32][Cout][32] layout); 4 = half-split: both operands as TWO
+ * half-precision planes h = rn(x 2^k), m = rn(x 2^k - h) (x carried to <= 2^-23 relative: within one fp32 ulp), three products
+ * h h' + h m' + m h' on v_mfma_f32_32x32x16_f16 (the dropped m m' is <= 2^-22, 2^-24 rms, of a term: below the rounding noise
+ * of the fp32 accumulation itself) - half the matrix work of mode 0 at the accuracy of an fp32 convolution.  The weight
+ * operand is then [2 planes][taps][Cin/32][Cout][32] half bit patterns of w 2^kw followed by ONE float = 2^-kw; the activation
+ * scale 2^k comes from fh_gn_epilogue.in_amax (fh_absmax_f32 of the input; required for fh_conv2d_x6_nhwc*) or is the fixed 2^4
+ * of the fused GroupNorm input (fh_conv2d_x6_norm_nhwc*: values beyond +-4094 saturate).
+ * Per calling host thread. */
 int fh_unet_set_precision(int mode);
+/* max over out[0 .. FH_AMAX_SLOTS) = max |x[i]| (all 0 for n = 0): the magnitude the half-split convolution scales its
+ * activation operand by.  FH_AMAX_SLOTS partial maxima instead of one value because same-address atomics serialise. */
+#define FH_AMAX_SLOTS 16
+int fh_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 int fh_conv2d_splitk(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 
 /* Same convolution as fh_conv2d_nhwc at fp32 accuracy on the bf16 matrix cores: operands are split exactly into three
@@ -323,6 +334,7 @@ typedef struct fh_gn_epilogue {
   const float* x;      /* mode 1: forward input of the GroupNorm, [N][Ho][Wo][Cout] */
   const float* tab;    /* mode 1: [N][5][Cout] from fh_groupnorm_bwd_table */
   int32_t mode, act;   /* act (mode 1): 1 = SiLU after the affine */
+  const float* in_amax; /* precision mode 4: device [FH_AMAX_SLOTS], max = max |in| (fh_absmax_f32); partial may then be null */
 } fh_gn_epilogue;
 int fh_conv2d_x6_gn_chunks(int ksplit, int N, int H, int W, int Cin, int Cout, int KH, int KW, int pad, int stride);
 int fh_conv2d_x6_nhwc_gn(const float* in, const void* wx, const float* bias, const float* res, float* out, float* ws,
@@ -344,10 +356,13 @@ int fh_groupnorm_bwd_sums(const float* x, const float* dy, const float* stats, c
  * (the gradient arriving over the block's skip path, openai_unet.py:256) and add2 (the gradient of a U-Net skip tensor, added
  * by autograd where `hs.append(h)` forked it, :663-671) may each be null; with dx2 != null the result is written as two
  * tensors, channels [0, csplit) -> dx [.., csplit] and [csplit, C) -> dx2 [.., C - csplit] - the gradient of
- * th.cat([h, hs.pop()], dim=1) (:682) without a split pass. */
+ * th.cat([h, hs.pop()], dim=1) (:682) without a split pass.  amax2 (nullable): [2][FH_AMAX_SLOTS] device floats the CALLER has
+ * zeroed; the pass folds max |dx| into [0][*] and max |dx2| into [1][*] - what fh_absmax_f32 would leave for them, for the half-split
+ * convolution (fh_unet_set_precision(4)) that consumes the gradient. */
 int fh_groupnorm_bwd_apply_ex(const float* x, const float* dy, const float* stats, const float* sums, const float* gamma,
                               const float* beta, const float* scale, const float* shift, int ss_stride, const float* acc_src,
-                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, void* stream);
+                              const float* add2, float* dx, float* dx2, int csplit, int N, int P, int C, int act, float* amax2,
+                              void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution with a thin output, Cout <= 8 (the 128 -> 6 output convolution and the
  * 128 -> 3 input gradient of the first one): direct form, w [Cout][9][Cin] as for fh_conv2d_nhwc, Cin % 32 == 0. */

@@ -620,3 +620,252 @@ def test_conv_group_sum_epilogue_fused_norm_input(dev):
     scr = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
     L.check(lib.fh_groupnorm_stats(out.data_ptr(), want.data_ptr(), scr.data_ptr(), N, H * W, Co, L.stream()), "stats")
     assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+
+
+# ---------------------------------------------------------------- half-split mode (fh_unet_set_precision(4), unet_dtype "fp16x3")
+def _half_split_conv(L, lib, xn, planes, b, rn, out, ws, ks, shape, amax_of=None):
+    """one fh_conv2d_x6_nhwc_gn launch in precision mode 4 (the input's magnitude through fh_gn_epilogue.in_amax)"""
+    import ctypes as C
+    N, H, W, Ci, Co, k, stride = shape
+    amax = torch.empty(16, device=xn.device)  # FH_AMAX_SLOTS
+    src = xn if amax_of is None else amax_of
+    L.check(lib.fh_absmax_f32(src.data_ptr(), src.numel(), amax.data_ptr(), L.stream()), "absmax")
+    e = L.FhGnEpilogue()
+    e.partial, e.in_amax = None, amax.data_ptr()
+    assert lib.fh_unet_set_precision(4) == 0
+    try:
+        L.check(lib.fh_conv2d_x6_nhwc_gn(xn.data_ptr(), planes.data_ptr(), None if b is None else b.data_ptr(),
+                                         None if rn is None else rn.data_ptr(), out.data_ptr(),
+                                         None if ws is None else ws.data_ptr(), ks, N, H, W, Ci, Co, k, k, k // 2, stride,
+                                         C.byref(e), L.stream()), "half-split")
+    finally:
+        lib.fh_unet_set_precision(0)
+    return amax
+
+
+HALF_SPLIT_SHAPES = [(1, 64, 64, 128, 128, 3, 1), (8, 64, 64, 128, 256, 3, 1), (1, 256, 256, 32, 128, 3, 1),
+                     (2, 128, 128, 64, 160, 3, 1), (16, 32, 32, 64, 384, 3, 1), (3, 8, 8, 160, 64, 3, 1),
+                     (2, 32, 32, 256, 320, 1, 1), (1, 33, 31, 64, 130, 3, 2), (4, 128, 256, 96, 128, 3, 1)]
+
+
+@pytest.mark.parametrize("mag", [1.0, 3e-7, 2e5])
+@pytest.mark.parametrize("shape", HALF_SPLIT_SHAPES)
+def test_conv_half_split_vs_float64(dev, shape, mag):
+    """Precision mode 4 (two half-precision planes per operand, three products on the f16 MFMA) against float64 - held to
+    the SAME bar as the exact bf16 split (test_conv_split_bf16_vs_float64): the error of an fp32 dot product, i.e. <= 1.5 x
+    that of the fp32-MFMA kernel on the same data and < 2e-6 of the output scale.  `mag` scales the input by 2e5 / 3e-7: the
+    power-of-two activation scale from fh_absmax_f32 keeps the planes inside the half-precision range (an input-gradient
+    tensor can have any magnitude)."""
+    from free_hunch_amd.unet_hip import _half_split_planes
+    L, lib = _lib()
+    N, H, W, Ci, Co, k, stride = shape
+    g = torch.Generator().manual_seed(sum(shape) + 5)
+    x = (torch.randn(N, Ci, H, W, generator=g) * (0.2 + 3 * torch.rand(N, Ci, H, W, generator=g)) * mag).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / math.sqrt(Ci * k * k)).to(dev)
+    b = (torch.randn(Co, generator=g) * mag).to(dev)
+    pad = k // 2
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=pad, stride=stride)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    res = (torch.randn(N, Co, Ho, Wo, generator=g) * mag).to(dev)
+    ref = ref + res.double()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    rn = res.permute(0, 2, 3, 1).contiguous()
+    wf = w.permute(0, 2, 3, 1).reshape(Co, k * k, Ci).contiguous()
+    planes = _half_split_planes(wf)
+    # the planes reproduce the weights to one fp32 ulp
+    body = planes[:-2].view(torch.float16).reshape(2, k * k, Ci // 32, Co, 32).float()
+    winv = float(planes[-2:].view(torch.float32))
+    back = (body.double().sum(0) * winv).permute(2, 0, 1, 3).reshape(Co, k * k, Ci)
+    # (one fp32 ulp; weights below 2^-16 of the largest leave m subnormal: absolute 2^-25 of the scaled unit instead)
+    assert bool(((back - wf.double()).abs() <= 2.0 ** -23 * wf.double().abs() + 2.0 ** -25 * winv).all())
+    errs = []
+    for which in ("half-split", "f32"):
+        out = torch.full((N, Ho, Wo, Co), float("nan"), device=dev)
+        if which == "f32":
+            L.check(lib.fh_conv2d_nhwc(xn.data_ptr(), wf.data_ptr(), b.data_ptr(), rn.data_ptr(), out.data_ptr(), None, 1,
+                                       N, H, W, Ci, Co, k, k, pad, stride, L.stream()), "f32")
+        else:
+            _half_split_conv(L, lib, xn, planes, b, rn, out, None, 1, shape)
+        errs.append(float((out.permute(0, 3, 1, 2).double() - ref).abs().max()))
+    scale = float(ref.abs().max())
+    assert errs[0] < 2e-6 * scale, (errs, scale)
+    assert errs[0] <= 1.5 * errs[1] + 1e-7 * scale, (errs, scale)
+
+
+def test_conv_half_split_splitk_and_missing_magnitude(dev):
+    """K-split launch of mode 4 (partials are un-scaled before they reach the workspace), and the error path: a raw-tensor
+    launch without the input's magnitude is refused."""
+    from free_hunch_amd.unet_hip import _half_split_planes
+    L, lib = _lib()
+    shape = (1, 8, 8, 512, 96, 3, 1)
+    N, H, W, Ci, Co, k, stride = shape
+    g = torch.Generator().manual_seed(78)
+    x = (torch.randn(N, Ci, H, W, generator=g) * 40).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    planes = _half_split_planes(w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous())
+    out = torch.empty(N, H, W, Co, device=dev)
+    ws = torch.empty(4, N * H * W, Co, device=dev)
+    amax = _half_split_conv(L, lib, xn, planes, b, None, out, ws, 4, shape)
+    assert float(amax.max()) == float(x.abs().max())
+    assert rel(out.permute(0, 3, 1, 2), ref) < 2e-6
+    assert lib.fh_unet_set_precision(4) == 0
+    try:
+        rc = lib.fh_conv2d_x6_nhwc(xn.data_ptr(), planes.data_ptr(), b.data_ptr(), None, out.data_ptr(), None, 1, N, H, W,
+                                   Ci, Co, 3, 3, 1, 1, L.stream())
+    finally:
+        lib.fh_unet_set_precision(0)
+    assert rc == -1
+    assert lib.fh_unet_set_precision(5) == -1
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 256, 64, 128, True), (8, 64, 64, 96, 256, False), (16, 32, 32, 64, 384, True)])
+def test_conv_half_split_fused_groupnorm_input(dev, shape):
+    """Mode 4 of fh_conv2d_x6_norm_nhwc (GroupNorm + SiLU applied while the tile is staged, fixed activation scale 2^4):
+    no further from a float64 GroupNorm -> SiLU -> conv than the exact split is (both carry the fp32 normalisation's
+    rounding), and the two agree to fp32 rounding."""
+    from free_hunch_amd.unet_hip import _half_split_planes, _split3
+    L, lib = _lib()
+    N, H, W, Ci, Co, with_ss = shape
+    g = torch.Generator().manual_seed(sum(shape[:5]) + 23)
+    x = (torch.randn(N, H, W, Ci, generator=g) * 1.7 + 0.3).to(dev)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(Ci * 9)).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    gamma, beta = (1 + 0.2 * torch.randn(Ci, generator=g)).to(dev), (0.1 * torch.randn(Ci, generator=g)).to(dev)
+    ss = (0.3 * torch.randn(N, 2 * Ci, generator=g)).to(dev) if with_ss else None
+    scale, shift = (ss[:, :Ci], ss[:, Ci:]) if with_ss else (None, None)
+    res = torch.randn(N, H, W, Co, generator=g).to(dev)
+    wf = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous()
+    st = L.stream()
+    stats = torch.empty(N, 32, 2, device=dev)
+    scratch = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
+    L.check(lib.fh_groupnorm_stats(x.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, Ci, st), "stats")
+    sp = lambda t: None if t is None else t.data_ptr()
+    stride = 0 if ss is None else ss.stride(0)
+    table = torch.empty(N, 2, Ci, device=dev)
+    L.check(lib.fh_groupnorm_table(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), sp(scale), sp(shift), stride,
+                                   table.data_ptr(), N, Ci, st), "table")
+    outs = {}
+    for mode, planes in ((0, _split3(wf)), (4, _half_split_planes(wf))):
+        out = torch.full((N, H, W, Co), float("nan"), device=dev)
+        assert lib.fh_unet_set_precision(mode) == 0
+        try:
+            L.check(lib.fh_conv2d_x6_norm_nhwc(x.data_ptr(), table.data_ptr(), 1, planes.data_ptr(), b.data_ptr(),
+                                               res.data_ptr(), out.data_ptr(), N, H, W, Ci, Co, st), "fused")
+        finally:
+            lib.fh_unet_set_precision(0)
+        outs[mode] = out.permute(0, 3, 1, 2)
+    xd = x.double().permute(0, 3, 1, 2)
+    ref = F.group_norm(xd, 32, gamma.double(), beta.double(), eps=1e-5)
+    if with_ss:
+        ref = ref * (1 + scale.double()[:, :, None, None]) + shift.double()[:, :, None, None]
+    ref = F.conv2d(F.silu(ref), w.double(), b.double(), padding=1) + res.double().permute(0, 3, 1, 2)
+    e0, e4 = rel(outs[0], ref), rel(outs[4], ref)
+    assert e4 < 2e-5 and e4 <= 1.25 * e0 + 2e-7, (e0, e4)
+    assert rel(outs[4], outs[0]) < 1e-6
+
+
+def test_half_split_mode_network_accuracy_vs_float64(dev, gold):
+    """unet_dtype "fp16x3" at network level.  The reference's float32 UNet (tests/golden/unet_a.npz) is itself only an
+    fp32 evaluation; the yardstick is the float64 evaluation of the same network (the PyTorch backend in double).  Asserted
+    for raw output and input-VJP at the three recorded noise levels: the half-split mode is no further from float64 than
+    1.25 x the exact-split default (+ 1e-7), both are as close to float64 as the reference's own float32 result is (x 1.5),
+    and the mode passes test_unet_hip_vs_reference_golden's bounds unchanged."""
+    from free_hunch_amd import unet as hu
+    from free_hunch_amd.precond import iDDPMLinearPrecond
+    g = gold("unet_a")
+    seed = int(g["seed"])
+    cfg = hu.UNetConfig(**{k: getattr(inputs.SMALL_A, k) for k in
+                           ("image_size", "num_channels", "num_res_blocks", "channel_mult", "learn_sigma",
+                            "attention_resolutions", "num_heads", "num_head_channels", "use_scale_shift_norm",
+                            "resblock_updown", "use_new_attention_order")})
+    sd = hu.seeded_state(cfg, seed)
+    x = (inputs.randn((1, 3, 64, 64), seed + 100) * 3.0).to(dev)
+    from unittest import mock
+    from oracle import unet_oracle as uo
+    sd64 = {k: v.double() for k, v in uo.seeded_state(inputs.SMALL_A, seed).items()}
+
+    def m64(xi, tstep):  # the oracle's network with every `.float()` of its GroupNorm32 / softmax made a `.double()` (CPU)
+        with mock.patch.object(torch.Tensor, "float", lambda self: self.double()):
+            return uo.unet_forward(sd64, inputs.SMALL_A, xi, tstep)
+    nets = {}
+    for mode in ("fp32", "fp16x3"):
+        m = hu.UNetModel(cfg, backend="hip", dtype=mode)
+        m.load_state_dict(sd)
+        nets[mode] = m.to(dev).eval()
+    rep = {}
+    for j in range(3):
+        sigma = torch.tensor(float(g[f"sigma_{j}"]), dtype=torch.float64, device=dev)
+        tstep = torch.from_numpy(g[f"tstep_{j}"]).long().flatten().to(dev)
+        c_in = 1 / (sigma ** 2 + 1).sqrt()
+        cot = inputs.randn((1, cfg.out_channels, 64, 64), seed + 300 + j).to(dev)
+        xi = (c_in * x.double()).float().double().cpu().requires_grad_()   # (the fp32 networks see the fp32 product)
+        y64 = m64(xi, tstep.cpu())
+        assert y64.dtype == torch.float64
+        (g64,) = torch.autograd.grad((y64 * cot.double().cpu()).sum(), xi)
+        y64, g64 = y64.detach().to(dev), g64.to(dev)
+        ref32 = torch.from_numpy(g[f"raw_{j}"]).to(dev)
+        res = {}
+        for mode, m in nets.items():
+            xi = (c_in.float() * x.float()).requires_grad_()
+            y = m(xi, tstep)
+            (gx,) = torch.autograd.grad((y * cot).sum(), xi)
+            res[mode] = (rel(y.detach(), y64.detach()), rel(gx, g64))
+            if mode == "fp16x3":
+                assert rel(y.detach(), ref32) < 5e-4
+                net = iDDPMLinearPrecond(m, 64, 3).to(dev)
+                xt = x.clone().requires_grad_()
+                D, _ = net(xt, sigma)
+                assert float((D - torch.from_numpy(g[f"D_{j}"]).to(dev)).abs().max()) < 1e-3
+                c2 = inputs.randn(D.shape, seed + 200 + j).to(D.dtype).to(dev)
+                (vjp,) = torch.autograd.grad((c2 * D).sum(), xt)
+                assert rel(vjp, torch.from_numpy(g[f"vjp_{j}"]).to(dev)) < 2e-3
+        e_ref = rel(ref32, y64.detach())
+        rep[j] = dict(sigma=float(sigma), fwd=dict(exact=res["fp32"][0], half_split=res["fp16x3"][0], reference_fp32=e_ref),
+                      vjp=dict(exact=res["fp32"][1], half_split=res["fp16x3"][1]))
+        assert res["fp16x3"][0] <= 1.25 * res["fp32"][0] + 1e-7, rep[j]
+        assert res["fp16x3"][1] <= 1.25 * res["fp32"][1] + 1e-7, rep[j]
+        assert res["fp16x3"][0] <= 1.5 * e_ref + 1e-7, rep[j]
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "half_split_report.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    json.dump(rep, open(path, "w"), indent=1)
+
+
+@pytest.mark.parametrize("split", [0, 64])
+def test_groupnorm_backward_apply_reports_output_magnitudes(dev, split):
+    """fh_groupnorm_bwd_apply_ex(amax2): the pass that writes a gradient tensor also leaves max |dx| (and max |dx2| of a split
+    result) - exactly fh_absmax_f32 of what it wrote - for the half-split convolution that reads the tensor next."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(31 + split)
+    N, H, W, C = 2, 33, 20, 160
+    xn = (torch.randn(N, H, W, C, generator=g) * 2 + 0.5).to(dev)
+    dyn = (torch.randn(N, H, W, C, generator=g) * 3e-4).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    acc = (torch.randn(N, H, W, C, generator=g) * 1e-4).to(dev)
+    st = L.stream()
+    stats, sums = torch.empty(N, 32, 2, device=dev), torch.empty(N, 32, 2, device=dev)
+    scratch = torch.empty(lib.fh_groupnorm_scratch_doubles(N, H * W), dtype=torch.float64, device=dev)
+    L.check(lib.fh_groupnorm_stats(xn.data_ptr(), stats.data_ptr(), scratch.data_ptr(), N, H * W, C, st), "stats")
+    L.check(lib.fh_groupnorm_bwd_sums(xn.data_ptr(), dyn.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None,
+                                      None, 0, sums.data_ptr(), scratch.data_ptr(), N, H * W, C, 1, st), "sums")
+    outs = []
+    for with_amax in (False, True):
+        dx = torch.full((N, H, W, split if split else C), float("nan"), device=dev)
+        dx2 = torch.full((N, H, W, C - split), float("nan"), device=dev) if split else None
+        amax = torch.zeros(2, 16, device=dev)  # [dx, dx2][FH_AMAX_SLOTS]
+        L.check(lib.fh_groupnorm_bwd_apply_ex(xn.data_ptr(), dyn.data_ptr(), stats.data_ptr(), sums.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), None, None, 0, acc.data_ptr(), None, dx.data_ptr(),
+                                              None if dx2 is None else dx2.data_ptr(), split, N, H * W, C, 1,
+                                              amax.data_ptr() if with_amax else None, st), "apply_ex")
+        outs.append((dx, dx2, amax))
+    assert torch.equal(outs[0][0], outs[1][0]) and (split == 0 or torch.equal(outs[0][1], outs[1][1]))
+    dx, dx2, amax = outs[1]
+    assert float(amax[0].max()) == float(dx.abs().max()) > 0
+    assert float(amax[1].max()) == (float(dx2.abs().max()) if split else 0.0)
+    one = torch.empty(16, device=dev)
+    L.check(lib.fh_absmax_f32(dx.data_ptr(), dx.numel(), one.data_ptr(), st), "absmax")
+    assert float(one.max()) == float(amax[0].max())
+    assert float(outs[0][2].abs().max()) == 0.0
