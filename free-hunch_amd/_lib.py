@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfh_hip.so")
+LIB_PATH = os.environ.get("FH_LIB_PATH") or os.path.join(_HERE, "libfh_hip.so")  # (FH_LIB_PATH: kernel experiments)
 
 c_dp = C.c_void_p  # device pointers travel as integers
 
@@ -108,6 +108,9 @@ _SIGS = {
     "fh_groupnorm_stats": ([c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_groupnorm_apply": ([c_dp] * 6 + [C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "fh_groupnorm_bwd": ([c_dp] * 7 + [C.c_int, c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
+    "fh_attention_supported": ([C.c_int] * 3, C.c_int),
+    "fh_attention_fwd": ([c_dp, c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),
+    "fh_attention_bwd": ([c_dp] * 6 + [C.c_int] * 5 + [C.c_void_p], C.c_int),
     "fh_softmax_rows": ([c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "fh_softmax_bwd_rows": ([c_dp, c_dp, C.c_int64, C.c_int, C.c_void_p], C.c_int),
     "fh_resample2x": ([c_dp, c_dp] + [C.c_int] * 5 + [C.c_void_p], C.c_int),

@@ -21,6 +21,9 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 namespace {
 
+#ifndef FH_EXP
+#define FH_EXP 0
+#endif
 constexpr int kBK = 32;       // K chunk (floats)
 constexpr int kLd = kBK + 4;  // LDS row stride in floats (144 B)
 
@@ -747,15 +750,27 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       const bool more = nx < nchunks, new_row = more && (nx % 3 == 0);
       if (more) {
         const int ncc = nx / 9, nky = (nx / 3) % 3, nkx = nx % 3;
+#if FH_EXP != 3
         issue_b(ncc, nky * 3 + nkx, nx & 1);  // buffer nx & 1 was last read in iteration c - 1, before its barrier
+#endif
+#if FH_EXP != 1
         if (new_row) load_a(ncc, nky);
+#endif
       }
+#if FH_EXP != 4
       compute(kx, c & 1);
+#endif
+#if FH_EXP != 2
       __syncthreads();
+#endif
+#if FH_EXP != 1
       if (new_row) {
         store_a();
+#if FH_EXP != 2
         __syncthreads();
+#endif
       }
+#endif
     }
   } else {
   load_a(0, 0);

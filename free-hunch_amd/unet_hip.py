@@ -476,6 +476,15 @@ class HipOps:
         T = H * W
         hn, st = self._gn(p + ".norm", x, act=0)
         qkv = self._conv(p + ".qkv", hn)  # [N,H,W,3C]
+        if os.environ.get("FH_ATTN_FUSED", "1") != "0" and self.lib.fh_attention_supported(T, C, heads):
+            # one kernel: q k^T -> online softmax -> . v; the tape keeps the output and the log-sum-exp, not the weights
+            A = torch.empty(N, H, W, C, dtype=torch.float32, device=x.device)
+            lse = torch.empty(N * heads, T, dtype=torch.float32, device=x.device)
+            _lib.check(self.lib.fh_attention_fwd(qkv.data_ptr(), A.data_ptr(), lse.data_ptr(), N, T, C, heads,
+                                                 int(self.cfg.use_new_attention_order), _lib.stream()), "attention_fwd")
+            out = self._conv(p + ".proj_out", A, res=x)
+            tape.append(("attn", p, x, st, qkv, (A, lse), heads))
+            return out
         ch, hs, qo, ko, vo = self._attn_geometry(N, T, C, heads)
         S = torch.empty(N * heads, T, T, dtype=torch.float32, device=x.device)
         base, fs = qkv.data_ptr(), 4
@@ -497,6 +506,14 @@ class HipOps:
         ch, hs, qo, ko, vo = self._attn_geometry(N, T, C, heads)
         gA = self._dgrad(p + ".proj_out", g)  # [N,H,W,C]
         dqkv = torch.empty_like(qkv)
+        if isinstance(S, tuple):  # fused form: the weights are recomputed from q, k and the log-sum-exp
+            A, lse = S
+            dsum = torch.empty_like(lse)
+            _lib.check(self.lib.fh_attention_bwd(qkv.data_ptr(), A.data_ptr(), gA.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+                                                 dqkv.data_ptr(), N, T, C, heads, int(self.cfg.use_new_attention_order),
+                                                 _lib.stream()), "attention_bwd")
+            g_hn = self._dgrad(p + ".qkv", dqkv, gn=(p + ".norm", x, st, 0, None, None))
+            return self._gn_bwd(p + ".norm", x, st, g_hn, 0, accumulate_into=g, add2=add2)
         base, dbase, fs = qkv.data_ptr(), dqkv.data_ptr(), 4
         s3, sS, sA = (T * 3 * C, hs), (heads * T * T, T * T), (T * C, ch)
         B_ = N * heads

@@ -398,6 +398,19 @@ int fh_groupnorm_bwd(const float* x, const float* dy, const float* stats, const 
 int fh_softmax_rows(float* s, int64_t rows, int T, void* stream);
 int fh_softmax_bwd_rows(const float* p, float* dp, int64_t rows, int T, void* stream);
 
+/* Fused self-attention of an AttentionBlock (training/openai_unet.py:296-305; head split and scaling of QKVAttentionLegacy
+ * :337-354 for new_order = 0, of QKVAttention :370-384 for new_order = 1), fp32 on v_mfma_f32_32x32x2_f32, the T x T weight
+ * matrix never written:
+ *   qkv [N][T][3C] (the qkv convolution's NHWC output)  ->  out [N][T][C] = softmax(q k^T / sqrt(ch)) v per (image, head),
+ *   lse [N * heads][T] = log2 sum_s exp2(log2(e) q_t k_s / sqrt(ch))   (kept for the backward instead of the weights).
+ * Backward (the weights are recomputed from q, k and lse, as the reference's checkpointed block recomputes its forward):
+ *   dqkv [N][T][3C] <- gradient w.r.t. qkv given dout = dL/dout; dsum [N * heads][T] is scratch (rowsum(dout . out)).
+ * No atomics: results are deterministic.  Supported: T % 32 == 0, C / heads in {32, 64} (fh_attention_supported; else FH_ESIZE). */
+int fh_attention_supported(int T, int C, int heads);
+int fh_attention_fwd(const float* qkv, float* out, float* lse, int N, int T, int C, int heads, int new_order, void* stream);
+int fh_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dsum, float* dqkv, int N,
+                     int T, int C, int heads, int new_order, void* stream);
+
 /* (Hs, Ws) = the SMALL side.  mode 0: 2x2 average pool big -> small; 1: its adjoint small -> big;
  * 2: nearest 2x upsample small -> big; 3: its adjoint big -> small; 4: zero insertion small -> big (value at (2h, 2w)). */
 int fh_resample2x(const float* in, float* out, int N, int Hs, int Ws, int C, int mode, void* stream);

@@ -869,3 +869,86 @@ def test_groupnorm_backward_apply_reports_output_magnitudes(dev, split):
     L.check(lib.fh_absmax_f32(dx.data_ptr(), dx.numel(), one.data_ptr(), st), "absmax")
     assert float(one.max()) == float(amax[0].max())
     assert float(outs[0][2].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------- fused attention (fh_attention_fwd / fh_attention_bwd)
+def _attention_float64(qkv, heads, new_order):
+    """QKVAttentionLegacy / QKVAttention of the reference (openai_unet.py:337-354 / :370-384) in float64 on [N][T][3C] tokens."""
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    ch = C // heads
+    x = qkv.transpose(1, 2)  # [N][3C][T] as the reference's conv1d output
+    if new_order:
+        q, k, v = x.chunk(3, dim=1)
+        q, k, v = (t.reshape(N * heads, ch, T) for t in (q, k, v))
+    else:
+        q, k, v = x.reshape(N * heads, ch * 3, T).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(N, C, T)
+    return a.transpose(1, 2)  # [N][T][C]
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 2, 0), (1, 256, 128, 2, 0), (2, 1024, 128, 2, 1), (3, 96, 128, 4, 1),
+                                   (1, 1024, 256, 4, 0), (2, 32, 64, 1, 0)])
+def test_fused_attention_vs_float64(dev, shape):
+    """One-kernel attention and its recomputing backward against the reference's two attention orders in float64: output,
+    dq / dk / dv within fp32 rounding (5e-6 of scale; the three-kernel path with materialised weights is held to the same),
+    and the two paths agree with each other to that order.  T = 96 (not a multiple of 128) exercises idle waves."""
+    L, lib = _lib()
+    N, T, C, heads, new_order = shape
+    assert lib.fh_attention_supported(T, C, heads) == 1
+    g = torch.Generator().manual_seed(sum(shape) + 3)
+    qkv = (torch.randn(N, T, 3 * C, generator=g) * 1.5).to(dev)
+    dout = torch.randn(N, T, C, generator=g).to(dev)
+    q64 = qkv.double().requires_grad_()
+    ref = _attention_float64(q64, heads, new_order)
+    (gref,) = torch.autograd.grad((ref * dout.double()).sum(), q64)
+    out = torch.full((N, T, C), float("nan"), device=dev)
+    lse = torch.full((N * heads, T), float("nan"), device=dev)
+    st = L.stream()
+    L.check(lib.fh_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), N, T, C, heads, new_order, st), "attn fwd")
+    assert rel(out, ref.detach()) < 5e-6
+    dqkv = torch.full((N, T, 3 * C), float("nan"), device=dev)
+    dsum = torch.empty_like(lse)
+    L.check(lib.fh_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+                                 dqkv.data_ptr(), N, T, C, heads, new_order, st), "attn bwd")
+    assert rel(dqkv, gref) < 5e-6
+    assert rel(dsum.reshape(N, heads, T), (ref.detach() * dout.double()).reshape(N, T, heads, C // heads).sum(-1).transpose(1, 2)) < 5e-6
+    # deterministic: a second run gives the same bits
+    dq2 = torch.empty_like(dqkv)
+    L.check(lib.fh_attention_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+                                 dq2.data_ptr(), N, T, C, heads, new_order, st), "attn bwd")
+    assert torch.equal(dq2, dqkv)
+
+
+def test_fused_attention_unsupported_shapes_fall_back(dev):
+    L, lib = _lib()
+    assert lib.fh_attention_supported(48, 64, 2) == 0      # T % 32 != 0
+    assert lib.fh_attention_supported(64, 96, 2) == 0      # head width 48
+    assert lib.fh_attention_supported(64, 256, 2) == 0     # head width 128
+    x = torch.zeros(1, 48, 192, device=dev)
+    o, l = torch.zeros(1, 48, 64, device=dev), torch.zeros(2, 48, device=dev)
+    assert lib.fh_attention_fwd(x.data_ptr(), o.data_ptr(), l.data_ptr(), 1, 48, 64, 2, 0, L.stream()) == -2
+
+
+def test_unet_fused_attention_equals_three_kernel_path(dev):
+    """Network level: forward and input-VJP with the fused attention (default) against the three-kernel path that keeps the
+    T x T weights on the tape (FH_ATTN_FUSED=0), legacy and new attention order."""
+    for cfg_o in (inputs.SMALL_A, NEW_ORDER):
+        (hip, _), cfg = _pair(cfg_o, 13, dev)
+        x = (inputs.randn((2, 3, 64, 64), 5, torch.float32) * 0.7).to(dev)
+        t = torch.tensor([400, 400], device=dev)
+        cot = inputs.randn((2, cfg.out_channels, 64, 64), 6, torch.float32).to(dev)
+        outs = []
+        for fused in ("1", "0"):
+            os.environ["FH_ATTN_FUSED"] = fused
+            try:
+                xi = x.clone().requires_grad_()
+                y = hip(xi, t)
+                (gx,) = torch.autograd.grad((y * cot).sum(), xi)
+            finally:
+                os.environ.pop("FH_ATTN_FUSED", None)
+            outs.append((y.detach(), gx))
+        assert rel(outs[0][0], outs[1][0]) < 2e-5
+        assert rel(outs[0][1], outs[1][1]) < 5e-5
