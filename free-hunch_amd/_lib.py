@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FH_LIB_PATH") or os.path.join(_HERE, "libfh_hip.so")  # (FH_LIB_PATH: kernel experiments)
+LIB_PATH = os.path.join(_HERE, "libfh_hip.so")
 
 c_dp = C.c_void_p  # device pointers travel as integers
 

@@ -21,9 +21,6 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 
 namespace {
 
-#ifndef FH_EXP
-#define FH_EXP 0
-#endif
 constexpr int kBK = 32;       // K chunk (floats)
 constexpr int kLd = kBK + 4;  // LDS row stride in floats (144 B)
 
@@ -556,21 +553,30 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_x6(ConvArgsX a) {
 // buffers, issued a tap ahead and retired by the single barrier of the tap (one barrier per tap instead of two).  The DMA
 // image is lane-linear (64-byte rows, no padding), so the bank spread of the 16-byte fragment reads comes from a swizzle of
 // the 16-byte chunk index with bits 2..3 of the row, applied on the per-lane SOURCE address and on the read.
-template <int SEGW, bool NORM = false, int BM = 128, int NP = 3, bool GL = false, bool F16 = false>  // SEGW: pixels per row segment of the tile (W, capped at BM)
+// GL = 2 (deep pipeline, half-split mode): with three products per tap instead of six a tap's MFMAs (~0.8 us) no longer
+// cover the L2 latency of the next tap's weight DMA, nor does the exposed activation staging hide behind anything.  So the
+// weight tiles go through a ring of THREE buffers issued two taps ahead, the activation tile is double-buffered (global
+// loads at the first tap of a kernel row, split + LDS write after the third tap's products, into the buffer the row before
+// last used), and the one barrier per tap waits with an explicit `s_waitcnt vmcnt(n)` that leaves the younger DMA / loads
+// in flight (a __syncthreads() would drain them).  Every wave issues exactly one DMA per tap and IA (+2 table) loads per
+// row, unconditionally, so the counts are exact.
+template <int SEGW, bool NORM = false, int BM = 128, int NP = 3, int GL = 0, bool F16 = false>  // SEGW: pixels per row segment of the tile (W, capped at BM)
 __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   constexpr int MI = 2, NI = 1, WN = 4, T = 4 * BM;
   constexpr int NSEG = BM / SEGW, SP = SEGW + 2;  // row segments per tile, staged pixels per segment (one halo each side)
   constexpr int BN = 128, AR = NSEG * SP;
   constexpr int IA = (AR * 8 + T - 1) / T;  // float4 items per thread for the activation tile (1040 items)
   constexpr int IB = (NP * BN * 4 + T - 1) / T;  // 16-byte items per thread for the weight tile (1536 items at NP = 3)
-  constexpr int NB = GL ? 2 : 1;          // (a second REGISTER-staged weight buffer was measured: no gain)
+  constexpr int NB = GL == 2 ? 3 : (GL ? 2 : 1);  // (a second REGISTER-staged weight buffer was measured: no gain)
+  constexpr int NA = GL == 2 ? 2 : 1;
+  static_assert(GL != 2 || (NP * 8 == T / 64), "deep pipeline: one weight DMA per wave and tap");
   constexpr int BLD = GL ? kBK : kXLd;    // weight-row stride in LDS
   // ONE __shared__ object for everything: beside an LDS-DMA staging array a second __shared__ object makes hipcc wait
   // vmcnt(0) before the first ds_read of every step, i.e. serialises the DMA with the MFMAs
-  constexpr int kAsBytes = NP * AR * kXLd * 2, kBsBytes = NB * NP * BN * BLD * 2;
+  constexpr int kAsBytes = NA * NP * AR * kXLd * 2, kBsBytes = NB * NP * BN * BLD * 2;
   constexpr int kGredBytes = (BM / 64) * WN * 32 * NI * 2 * 8;
   __shared__ __align__(16) unsigned char smem[kAsBytes + kBsBytes + kGredBytes];
-  __bf16 (*As)[AR][kXLd] = reinterpret_cast<__bf16 (*)[AR][kXLd]>(smem);
+  __bf16 (*As)[NP][AR][kXLd] = reinterpret_cast<__bf16 (*)[NP][AR][kXLd]>(smem);
   __bf16 (*Bs)[NP][BN][BLD] = reinterpret_cast<__bf16 (*)[NP][BN][BLD]>(smem + kAsBytes);
   double* gred = reinterpret_cast<double*>(smem + kAsBytes + kBsBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -627,8 +633,13 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       const int gy = py + a_seg[e] + ky - 1;
       const bool ok = a_in[e] && gy >= 0 && gy < a.H;
       ra_ok[e] = ok;
-      ra_reg[e] = ok ? *reinterpret_cast<const float4*>(base + ((int64_t)gy * a.W + a_gx[e]) * a.Cin)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GL == 2) {  // always issued (clamped address): the explicit vmcnt waits count on IA loads per wave
+        const float4 v = *reinterpret_cast<const float4*>(base + ((int64_t)(ok ? gy : 0) * a.W + (ok ? a_gx[e] : 0)) * a.Cin);
+        ra_reg[e] = v;  // (masked in store_a, a barrier later: a select here would let the compiler branch around the load)
+      } else {
+        ra_reg[e] = ok ? *reinterpret_cast<const float4*>(base + ((int64_t)gy * a.W + a_gx[e]) * a.Cin)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto load_b = [&](int cc, int tap) {
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
     }
   };
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-  auto store_a = [&]() {
+  auto store_a = [&](int abuf = 0) {
 #pragma unroll
     for (int e = 0; e < IA; ++e) {
       if (a_row[e] < 0) continue;
@@ -668,6 +679,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float x = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+        if (GL == 2 && !NORM) x = ra_ok[e] ? x : 0.f;
         if (NORM) {
           const float ta = q == 0 ? tA.x : q == 1 ? tA.y : q == 2 ? tA.z : tA.w;
           const float tb = q == 0 ? tB.x : q == 1 ? tB.y : q == 2 ? tB.z : tB.w;
@@ -684,9 +696,9 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
         }
         h4[q] = h, m4[q] = m, l4[q] = l;
       }
-      *reinterpret_cast<bf16x4_t*>(&As[0][a_row[e]][a_c4]) = h4;
-      if (NP >= 2) *reinterpret_cast<bf16x4_t*>(&As[NP >= 2 ? 1 : 0][a_row[e]][a_c4]) = m4;
-      if (NP == 3) *reinterpret_cast<bf16x4_t*>(&As[NP - 1][a_row[e]][a_c4]) = l4;
+      *reinterpret_cast<bf16x4_t*>(&As[abuf][0][a_row[e]][a_c4]) = h4;
+      if (NP >= 2) *reinterpret_cast<bf16x4_t*>(&As[abuf][NP >= 2 ? 1 : 0][a_row[e]][a_c4]) = m4;
+      if (NP == 3) *reinterpret_cast<bf16x4_t*>(&As[abuf][NP - 1][a_row[e]][a_c4]) = l4;
     }
   };
   auto store_b = [&](int buf) {
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
   int arow[MI];  // staged row of this lane's pixel: pixel j of the tile sits at j + 2 * (j / SEGW) + 1, tap kx at - 1 + kx
 #pragma unroll
   for (int i = 0; i < MI; ++i) arow[i] = wm + i * 32 + lr + 2 * ((wm + i * 32 + lr) / SEGW);
-  auto compute = [&](int kx, int bbuf) {
+  auto compute = [&](int kx, int bbuf, int abuf = 0) {
 #pragma unroll
     for (int ks = 0; ks < kBK / 16; ++ks) {
       const int ko = ks * 16 + 8 * lh;
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[p][arow[i] + kx][ko]);
+        for (int i = 0; i < MI; ++i) af[p][i] = *reinterpret_cast<const bf16x8_t*>(&As[abuf][p][arow[i] + kx][ko]);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int brow = wn + j * 32 + lr;
@@ -740,7 +752,70 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
     }
   };
   // chunk c = (cc * 3 + ky) * 3 + kx
-  if (GL) {
+  if (GL == 2) {
+    // s_waitcnt as the BUILTIN: the compiler's wait-count pass reads it and knows what is still in flight afterwards (after
+    // an inline-asm wait it assumed everything was, and drained the fresh DMA with a vmcnt(0) at the first use of the row's
+    // loads).  Immediate (gfx9): vmcnt = bits 3:0, expcnt = 6:4 (7 = no wait), lgkmcnt = 11:8 (0: LDS reads / writes done).
+    // sched_barrier: the machine scheduler would otherwise lift store_a's register arithmetic across the barrier into the
+    // earlier taps; the empty asm keeps the compiler's LDS / global accesses on their side of it.
+#define FH_WAIT_BARRIER(n)                          \
+  do {                                              \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_s_waitcnt(0x0070 | (n));       \
+    __builtin_amdgcn_s_barrier();                   \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+    constexpr int kLoads = IA + (NORM ? 2 : 0);  // global loads of one activation row group per wave
+    static_assert(kLoads + 1 == 4 || kLoads + 1 == 6, "FH_WAIT_BARRIER immediates below");
+    load_a(0, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 1, 1);
+    store_a(0);
+    FH_WAIT_BARRIER(0);
+    // one iteration = one (channel chunk, kernel row) = three taps in ring slots 0, 1, 2; straight-line so that the
+    // compiler's own wait-count model sees the row's loads retired at store_a (with the taps as a runtime switch it
+    // drained everything at the head of the next row)
+    auto tap_args = [&](int c, int& cc, int& tap) { cc = c / 9, tap = ((c / 3) % 3) * 3 + c % 3; };
+    const int nrg = nchunks / 3;
+    int cc, tap;
+    for (int rg = 0; rg + 1 < nrg; ++rg) {  // (the last row is peeled: nothing conditional inside, the model stays exact)
+      const int c0 = 3 * rg, ab = rg & 1;
+      // tap 0: [DMA(c0 + 1) from the tap before] loads of the next row, DMA(c0 + 2) -> only the oldest must have landed
+      load_a((rg + 1) / 3, (rg + 1) % 3);
+      tap_args(c0 + 2, cc, tap);
+      issue_b(cc, tap, 2);
+      compute(0, 0, ab);
+      if (kLoads + 1 == 4)
+        FH_WAIT_BARRIER(4);
+      else
+        FH_WAIT_BARRIER(6);
+      // tap 1: DMA(c0 + 2) must have landed, this tap's DMA(c0 + 3) may fly (the loads, which the scheduler may have put
+      // before the older DMA, are waited for too: they have had a whole tap)
+      tap_args(c0 + 3, cc, tap);
+      issue_b(cc, tap, 0);
+      compute(1, 1, ab);
+      FH_WAIT_BARRIER(1);
+      // tap 2: products, then the next row's tile into the other activation buffer (last read in row rg - 1)
+      tap_args(c0 + 4, cc, tap);
+      issue_b(cc, tap, 1);
+      compute(2, 2, ab);
+      store_a(ab ^ 1);
+      FH_WAIT_BARRIER(1);
+    }
+    {
+      const int c0 = 3 * (nrg - 1), ab = (nrg - 1) & 1;
+      tap_args(c0 + 2, cc, tap);
+      issue_b(cc, tap, 2);
+      compute(0, 0, ab);
+      FH_WAIT_BARRIER(1);
+      compute(1, 1, ab);
+      FH_WAIT_BARRIER(0);
+      compute(2, 2, ab);
+    }
+#undef FH_WAIT_BARRIER
+  } else if (GL) {
     load_a(0, 0);
     issue_b(0, 0, 0);
     store_a();
@@ -750,27 +825,15 @@ __global__ __launch_bounds__(4 * BM, 4) void k_conv_x6r(ConvArgsX a) {
       const bool more = nx < nchunks, new_row = more && (nx % 3 == 0);
       if (more) {
         const int ncc = nx / 9, nky = (nx / 3) % 3, nkx = nx % 3;
-#if FH_EXP != 3
         issue_b(ncc, nky * 3 + nkx, nx & 1);  // buffer nx & 1 was last read in iteration c - 1, before its barrier
-#endif
-#if FH_EXP != 1
         if (new_row) load_a(ncc, nky);
-#endif
       }
-#if FH_EXP != 4
       compute(kx, c & 1);
-#endif
-#if FH_EXP != 2
       __syncthreads();
-#endif
-#if FH_EXP != 1
       if (new_row) {
         store_a();
-#if FH_EXP != 2
         __syncthreads();
-#endif
       }
-#endif
     }
   } else {
   load_a(0, 0);
@@ -1728,12 +1791,13 @@ static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, co
     const bool big = r3 && !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
     const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
     static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;  // weight tile by LDS-DMA (default; 0 = register staging, the A/B switch)
+    static const int deep = getenv("FH_X6_DEEP") ? atoi(getenv("FH_X6_DEEP")) : 1;  // half-split mode: three-slot weight ring + double-buffered activations (0 = the two-slot pipeline, the A/B switch)
     if (big && glds && W % 256 == 0)
-      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), (k_conv_x6r<256, false, 256, 1, true, true>), (k_conv_x6r<256, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<256, false, 256, 1, true>), (k_conv_x6r<256, false, 256, 2, true>), (k_conv_x6r<256, false, 256, 3, true>), (k_conv_x6r<256, false, 256, 1, true, true>), (deep ? k_conv_x6r<256, false, 256, 2, 2, true> : k_conv_x6r<256, false, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 128 && H % 2 == 0)
-      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), (k_conv_x6r<128, false, 256, 1, true, true>), (k_conv_x6r<128, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<128, false, 256, 1, true>), (k_conv_x6r<128, false, 256, 2, true>), (k_conv_x6r<128, false, 256, 3, true>), (k_conv_x6r<128, false, 256, 1, true, true>), (deep ? k_conv_x6r<128, false, 256, 2, 2, true> : k_conv_x6r<128, false, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
     else if (big && glds && W == 64 && H % 4 == 0)
-      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), (k_conv_x6r<64, false, 256, 1, true, true>), (k_conv_x6r<64, false, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+      X6_DISPATCH((k_conv_x6r<64, false, 256, 1, true>), (k_conv_x6r<64, false, 256, 2, true>), (k_conv_x6r<64, false, 256, 3, true>), (k_conv_x6r<64, false, 256, 1, true, true>), (deep ? k_conv_x6r<64, false, 256, 2, 2, true> : k_conv_x6r<64, false, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W % 256 == 0)
       X6_DISPATCH((k_conv_x6r<256, false, 256, 1>), (k_conv_x6r<256, false, 256, 2>), (k_conv_x6r<256, false, 256, 3>), (k_conv_x6r<256, false, 256, 1, false, true>), (k_conv_x6r<256, false, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
     else if (big && W == 128 && H % 2 == 0)
@@ -1836,12 +1900,13 @@ static int conv2d_x6_norm_impl(const float* in, const float* ab_table, int act, 
   const bool big = !no_big && M % 256 == 0 && (M / 256) * ((Cout + 127) / 128) >= 256;
   const dim3 gbig((unsigned)(M / 256), (Cout + 127) / 128, 1);
   static const int glds = getenv("FH_X6_GLDS") ? atoi(getenv("FH_X6_GLDS")) : 1;
+  static const int deep = getenv("FH_X6_DEEP") ? atoi(getenv("FH_X6_DEEP")) : 1;
   if (big && glds && W % 256 == 0)
-    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), (k_conv_x6r<256, true, 256, 1, true, true>), (k_conv_x6r<256, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<256, true, 256, 1, true>), (k_conv_x6r<256, true, 256, 2, true>), (k_conv_x6r<256, true, 256, 3, true>), (k_conv_x6r<256, true, 256, 1, true, true>), (deep ? k_conv_x6r<256, true, 256, 2, 2, true> : k_conv_x6r<256, true, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 128 && H % 2 == 0)
-    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), (k_conv_x6r<128, true, 256, 1, true, true>), (k_conv_x6r<128, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<128, true, 256, 1, true>), (k_conv_x6r<128, true, 256, 2, true>), (k_conv_x6r<128, true, 256, 3, true>), (k_conv_x6r<128, true, 256, 1, true, true>), (deep ? k_conv_x6r<128, true, 256, 2, 2, true> : k_conv_x6r<128, true, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
   else if (big && glds && W == 64 && H % 4 == 0)
-    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), (k_conv_x6r<64, true, 256, 1, true, true>), (k_conv_x6r<64, true, 256, 2, true, true>), gbig, dim3(1024), 0, st, a);
+    X6_DISPATCH((k_conv_x6r<64, true, 256, 1, true>), (k_conv_x6r<64, true, 256, 2, true>), (k_conv_x6r<64, true, 256, 3, true>), (k_conv_x6r<64, true, 256, 1, true, true>), (deep ? k_conv_x6r<64, true, 256, 2, 2, true> : k_conv_x6r<64, true, 256, 2, 1, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W % 256 == 0)
     X6_DISPATCH((k_conv_x6r<256, true, 256, 1>), (k_conv_x6r<256, true, 256, 2>), (k_conv_x6r<256, true, 256, 3>), (k_conv_x6r<256, true, 256, 1, false, true>), (k_conv_x6r<256, true, 256, 2, false, true>), gbig, dim3(1024), 0, st, a);
   else if (big && W == 128 && H % 2 == 0)
