@@ -1680,7 +1680,7 @@ int fh_conv2d_nhwc(const float* in, const float* w, const float* bias, const flo
                    void* stream) {
   if (!in || !w || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
     return FH_EINVAL;
-  if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
+  if (ksplit < 1 || ksplit > 32 || (ksplit > 1 && !ws)) return FH_EINVAL;
   ConvArgs a;
   a.in = in, a.w = w, a.bias = bias, a.res = res, a.out = out;
   a.N = N, a.H = H, a.W = W, a.Cin = Cin, a.Cout = Cout, a.KH = KH, a.KW = KW, a.pad = pad, a.stride = stride;
@@ -1767,7 +1767,7 @@ static int conv2d_x6_impl(const float* in, const void* wx, const float* bias, co
                           const fh_gn_epilogue* epi, void* stream) {
   if (!in || !wx || !out || N < 1 || H < 1 || W < 1 || Cin < kBK || Cin % kBK != 0 || Cout < 1 || stride < 1)
     return FH_EINVAL;
-  if (ksplit < 1 || ksplit > 8 || (ksplit > 1 && !ws)) return FH_EINVAL;
+  if (ksplit < 1 || ksplit > 32 || (ksplit > 1 && !ws)) return FH_EINVAL;
   ConvArgsX a;
   a.ab = nullptr, a.act = 0;
   {

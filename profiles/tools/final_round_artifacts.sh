@@ -7,6 +7,7 @@ tail -c 600 gpurun_out/r03_bench_line.json; echo
 rm -rf gpurun_out/prof_bench
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --no-cpu-baseline > gpurun_out/r03_bench_profiled_line.json 2>/dev/null
 cp gpurun_out/prof_bench/*/*kernel_stats.csv gpurun_out/r03_bench_ffhq_gblur_heun30_b8_kernel_stats.csv
+python3 bench.py --no-cpu-baseline --unet-dtype fp16x3 > gpurun_out/r03_bench_line_fp16x3_mode.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --unet-dtype fp16 > gpurun_out/r03_bench_line_fp16_mode.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --unet-dtype bf16 > gpurun_out/r03_bench_line_bf16_mode.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --unet-dtype bf16x3 > gpurun_out/r03_bench_line_bf16x3_mode.json 2>/dev/null
