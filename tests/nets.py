@@ -47,12 +47,12 @@ def _hip_cfg(cfg_in):
                              "resblock_updown", "use_new_attention_order")})
 
 
-def damped_hip_net(cfg_in, seed, dev, damp=inputs.DAMP):
-    """The HIP UNet with inputs.damped_state weights (the recording side: make_golden.damped_net)."""
+def damped_hip_net(cfg_in, seed, dev, damp=inputs.DAMP, dtype=None):
+    """The HIP UNet with inputs.damped_state weights (the recording side: make_golden.damped_net); `dtype`: UNetModel.set_dtype."""
     from free_hunch_amd import unet as hu
     from free_hunch_amd.precond import iDDPMLinearPrecond
     cfg = _hip_cfg(cfg_in)
-    model = hu.UNetModel(cfg, backend=os.environ.get("FH_UNET_BACKEND", "hip"))
+    model = hu.UNetModel(cfg, backend=os.environ.get("FH_UNET_BACKEND", "hip"), dtype=dtype or "fp32")
     model.load_state_dict(inputs.damped_state(hu.seeded_state, cfg, seed, damp))
     return iDDPMLinearPrecond(model.to(dev).eval(), cfg.image_size, 3).to(dev)
 

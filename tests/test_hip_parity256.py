@@ -538,6 +538,20 @@ def test_free_running_converged_256_within_1e3(dev, gold, tag):
     assert abs(float(g[p + "x_final_absmax"]) - rec["ref_abs_max"]) < 1.0  # (the strided sample is representative)
 
 
+@pytest.mark.parametrize("tag", [t for t in TIGHT_256 if t.endswith("_damped")])
+def test_free_running_converged_256_within_1e3_half_split_unet(dev, gold, tag):
+    """The same end-to-end bar with the UNet in the opt-in half-split mode (`unet_dtype = fp16x3`: two half-precision planes
+    per convolution operand, three products): the two recordings that run the HIP UNet, same assertions - identical k and
+    branch lists, iteration counts within 4 % + 2, final image within 1e-3 max-abs of the REFERENCE's recording."""
+    g = gold("trajectories256_tight")
+    net = nets.damped_hip_net(inputs.SMALL_C, int(g["unet_seed"]), dev, dtype="fp16x3")
+    rec, tr = _free_run(g, tag, 256, net, dev, DATA, 2, "hip-damped-fp16x3")
+    assert rec["k_equal"], rec
+    assert rec["branch_mismatch_calls"] == 0, rec
+    assert all(abs(a - b) <= 0.04 * b + 2 for a, b in zip(rec["niter_hip"], rec["niter_ref"])), rec
+    assert rec["final_max_abs"] < 1e-3, rec
+
+
 def test_free_running_sr256_with_reference_unet_arithmetic(dev, gold):
     """The well-conditioned full-size case with the oracle's CPU UNet (the reference's denoiser arithmetic) against the
     reference's 256 x 256 Heun-30 recording (which the oracle reproduces exactly on the recording host:
