@@ -170,14 +170,17 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
         return e0.elapsed_time(e1) / 1e3 / iters
 
     # What the samplers issue: the two-pass kernels (k_rep_dots + k_rep_coef + k_rep_apply2).  The single-sweep kernel
-    # (k_rep_fused: B stays in registers between the reduction and the product; opt-in, fh_context_set_exclusive(ctx, 2)) is
-    # timed beside it - bitwise equal, read-once traffic, but not faster (profiles/r02_cov_apply_single_sweep.md).
+    # (k_rep_fused: B stays in registers between the reduction and the product; opt-in, fh_context_set_exclusive(ctx, 2);
+    # bitwise equal, read-once traffic, but not faster: profiles/r02_cov_apply_single_sweep.md) is a profiling variant: it
+    # is timed beside the product's kernels only on request (FH_BENCH_SINGLE_SWEEP=1), not in the default bench run.
     ctx.set_exclusive(1)
     sec = timed()
     ctx.status()
-    ctx.set_exclusive(2)
-    sec_alt = timed()
-    ctx.status()
+    sec_alt = None
+    if os.environ.get("FH_BENCH_SINGLE_SWEEP") == "1":
+        ctx.set_exclusive(2)
+        sec_alt = timed()
+        ctx.status()
     ctx.set_exclusive(0)
     algo_bytes = nimg * (8 * d * m + 8 * d * 4)  # per image: base once + D, r, z read + out written (float64)
     achieved = algo_bytes / sec / 1e9
@@ -189,15 +192,17 @@ def roofline_cov_apply(device, m=32, iters=200, nimg=1):
         # the one-image file holds the single-sweep kernel's counters, the two-pass ones under "two_pass_for_comparison"
         traffic = (rec.get("two_pass_for_comparison", {}) if nimg == 1 else rec).get("traffic_bytes_per_apply")
     two_pass, fused = "k_rep_dots + k_rep_coef + k_rep_apply2 (two sweeps of B)", "k_rep_fused<4> (single sweep: B read once)"
-    return {"bound": "hbm", "kernel": f"fh_rep_apply = {two_pass}; d=196608, m={m}, f64, "
+    line = {"bound": "hbm", "kernel": f"fh_rep_apply = {two_pass}; d=196608, m={m}, f64, "
                                       f"{nimg} image{'s' if nimg > 1 else ''} per launch",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2),
-            "other_variant": {"kernel": fused,
-                              "achieved": round(algo_bytes / sec_alt / 1e9, 1), "unit": "GB/s",
-                              "frac": round(algo_bytes / sec_alt / 1e9 / HBM_PEAK_GBS, 4),
-                              "us_per_apply": round(sec_alt * 1e6, 2)}}
+            "algorithmic_bytes": algo_bytes, "us_per_apply": round(sec * 1e6, 2)}
+    if sec_alt is not None:
+        line["other_variant"] = {"kernel": fused,
+                                 "achieved": round(algo_bytes / sec_alt / 1e9, 1), "unit": "GB/s",
+                                 "frac": round(algo_bytes / sec_alt / 1e9 / HBM_PEAK_GBS, 4),
+                                 "us_per_apply": round(sec_alt * 1e6, 2)}
+    return line
 
 
 def roofline_dense_cov_apply(device, d=12288, iters=30):
