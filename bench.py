@@ -534,6 +534,8 @@ def main():
     ap.add_argument("--unet-dtype", default="fp32", choices=["fp32", "fp16x3", "bf16x3", "bf16", "fp16"],
                     help="bf16: reduced-precision torso (non-parity speed mode, reported separately from the fp32 headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-half-split-leg", action="store_true",
+                    help="skip the extra leg that times the same workload with --unet-dtype fp16x3 (N = 1, fp32 runs only)")
     ap.add_argument("--cpu-calls", type=int, default=2, help="real UNet calls timed by the CPU-baseline leg")
     a = ap.parse_args()
 
@@ -610,6 +612,26 @@ def main():
             line["roofline_cov_apply_b1"] = roofline_cov_apply(device, nimg=1)
         line["roofline_unet_conv"] = roofline_conv_mfma(device)
         line["roofline_dense_cov_apply"] = roofline_dense_cov_apply(device)
+        if world == 1 and a.unet_dtype == "fp32" and a.unet_backend == "hip" and not a.no_half_split_leg:
+            # The same workload once more with the opt-in half-split convolutions, measured in the same
+            # process on the same box, so that the two figures can be compared without the box-to-box spread.  Reported
+            # beside the headline, never as `value`.
+            del net
+            net2, _ = build_net(a.arch, device, a.unet_backend, "fp16x3")
+            k = max(1, min(a.steps, 3))
+
+            def step2(i):
+                seeds = [i * a.batch + j for j in range(a.batch)]
+                return run_batch(net2, images, seeds, a.operator, a.num_steps, a.solver, device, data_dir, a.groups)
+
+            t2 = run_steps(step2, k, 1, 1, coll, torch.cuda.synchronize)
+            line["half_split_mode"] = {
+                "value": round(k * a.batch / t2, 5), "unit": "images/s", "steps": k, "warmup": 1,
+                "ms_per_step": round(t2 / k * 1e3, 2), "flag": "--unet-dtype fp16x3",
+                "dtype": "f32 UNet with the 3x3 convolutions as 3 half-precision products of 2-plane operands, fp32 accumulation "
+                         "(fp32-convolution accuracy against float64: tests/test_hip_unet.py::test_half_split_*; not "
+                         "bit-comparable with the exact split, hence opt-in) + f64 covariance/CG"}
+            del net2
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.arch, a.operator, a.num_steps, data_dir, a.cpu_calls, a.solver)
         print(json.dumps(line), flush=True)
