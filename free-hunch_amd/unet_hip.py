@@ -476,7 +476,8 @@ class HipOps:
         T = H * W
         hn, st = self._gn(p + ".norm", x, act=0)
         qkv = self._conv(p + ".qkv", hn)  # [N,H,W,3C]
-        if os.environ.get("FH_ATTN_FUSED", "1") != "0" and self.lib.fh_attention_supported(T, C, heads):
+        if (os.environ.get("FH_ATTN_FUSED", "1") != "0" and self.lib.fh_attention_supported(T, C, heads)
+                and N * heads <= 65535):  # (image, head) pairs ride in gridDim.y
             # one kernel: q k^T -> online softmax -> . v; the tape keeps the output and the log-sum-exp, not the weights
             A = torch.empty(N, H, W, C, dtype=torch.float32, device=x.device)
             lse = torch.empty(N * heads, T, dtype=torch.float32, device=x.device)
