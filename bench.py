@@ -104,7 +104,9 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     def run_group(g):
         lo, hi = bounds[g], bounds[g + 1]
         torch.cuda.set_device(dev_index)
-        stream = torch.cuda.Stream(device=device)
+        stream = _GROUP_STREAMS.get((dev_index, g))  # one stream per group for the life of the process (the caching
+        if stream is None:                            # allocator reuses a stream's freed blocks only on that stream)
+            stream = _GROUP_STREAMS[(dev_index, g)] = torch.cuda.Stream(device=device)
         with torch.cuda.stream(stream):
             stream.wait_event(ready)
             x = conditional_sampler_batched(net, torch.cat(noises[lo:hi], 0).to(device), ys[lo:hi], ops[lo:hi],
@@ -125,6 +127,9 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
         main.wait_event(done)
     run_batch.cg_iters = [n for r in res for n in r[2]]
     return torch.cat([r[0] for r in res], 0)
+
+
+_GROUP_STREAMS = {}
 
 
 def _latest_profile(suffix):

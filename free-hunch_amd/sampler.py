@@ -114,6 +114,19 @@ def conditional_sampler(net, noise, cond_images, operator_kwargs, noise_kwargs=N
     return x_next, x_all, cond_images
 
 
+_IMAGE_STREAMS = {}
+_IMAGE_STREAMS_LOCK = __import__("threading").Lock()
+
+
+def _image_stream(device_index, slot, dev):
+    """The HIP stream of lock-step image `slot` on this device (one per slot for the life of the process)."""
+    with _IMAGE_STREAMS_LOCK:
+        st = _IMAGE_STREAMS.get((device_index, slot))
+        if st is None:
+            st = _IMAGE_STREAMS[(device_index, slot)] = torch.cuda.Stream(device=dev)
+        return st
+
+
 def conditional_sampler_batched(net, noise, measurements, operators, num_steps=18, sigma_min=None, sigma_max=None,
                                 rho=7, solver="heun", slot_base=0, batched_cg=True, **other_args):
     """B independent images advanced in lock-step (BASELINE.json config 2, "batch = 8"): every guidance call runs
@@ -150,7 +163,13 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
     # the batched CG runs alone on the GPU unless the caller overlaps several lock-step groups (bench.py --groups > 1)
     exclusive_cg = bool(o.get("exclusive_device", True))
     ys = [m.to(dev) for m in measurements]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
+    # The per-image streams are created ONCE per (device, slot) and kept: the caching allocator keeps freed blocks per stream,
+    # and `torch.cuda.Stream()` hands out the 32 pool streams round-robin - with fresh Stream objects per batch the covariance
+    # buffers and UNet activations landed on a different pool stream every batch, no stream ever found its own freed blocks,
+    # and the process reserved 10 GB more per batch (0.3-0.5 s of hipMalloc per batch, then a multi-second cache flush at the
+    # 288 GB limit after ~25 batches).
+    device_key = dev.index if dev.index is not None else torch.cuda.current_device()
+    streams = [_image_stream(device_key, slot_base + b, dev) for b in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
     device_index = dev.index if dev.index is not None else torch.cuda.current_device()
 
@@ -177,8 +196,12 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
 
     prof = {"fwd": 0.0, "update": 0.0, "solve": 0.0, "vjp": 0.0, "finish": 0.0} if _os.environ.get("FH_PHASE_TIMES") else None
     if prof is not None:
+        prof["mech_host"] = _time.perf_counter() - _t_mech
         torch.cuda.synchronize()
         prof["mechanisms"] = _time.perf_counter() - _t_mech
+        prof["mem_reserved_GB"] = round(torch.cuda.memory_reserved() / 2**30, 1)
+        prof["mem_alloc_GB"] = round(torch.cuda.memory_allocated() / 2**30, 1)
+        prof["n_mallocs"] = torch.cuda.memory_stats().get("num_device_alloc", -1)
         _t_loop = _time.perf_counter()
 
     # Host <-> device rendezvous after the two UNet passes.  Nothing needs it for correctness (the streams are ordered by
@@ -274,7 +297,7 @@ def conditional_sampler_batched(net, noise, measurements, operators, num_steps=1
     if prof is not None:
         torch.cuda.synchronize()
         prof["loop_total"] = _time.perf_counter() - _t_loop
-        print("[FH_PHASE_TIMES] seconds per batch:", {k: round(v, 3) for k, v in prof.items()}, flush=True)
+        print("[FH_PHASE_TIMES] seconds per batch:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in prof.items()}, flush=True)
     conditional_sampler_batched.last_mechanisms = mechs
     conditional_sampler_batched.tls.mechanisms = mechs  # per host thread (several groups may run concurrently)
     return x_next

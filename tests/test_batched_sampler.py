@@ -40,3 +40,45 @@ def test_batched_equals_per_image(gold, tmp_path):
         assert [t["k"] for t in t1] == [t["k"] for t in tb]
         # the UNet sums over a different tile partition at batch 3 vs batch 1: float32-level differences only
         assert float((x1 - xb[b:b + 1]).abs().max()) < 1e-3
+
+
+def test_repeated_batches_reuse_device_memory(gold, tmp_path):
+    """Successive lock-step batches must not grow the process's device memory: the per-image side streams are created once per
+    slot and kept, so the caching allocator finds each stream's freed covariance buffers and activations again (with fresh
+    Stream objects per batch it reserved 10 GB more per 256 x 256 batch - 0.3-0.5 s of hipMalloc per batch and a
+    multi-second cache flush at the 288 GB limit after ~25 batches of bench.py)."""
+    from free_hunch_amd.measurements import get_operator
+    from free_hunch_amd.sampler import conditional_sampler_batched
+    from test_hip_parity import _hip_net, _base_kwargs
+    dev = torch.device("cuda:0")
+    g = gold("trajectories")
+    torch.save(torch.from_numpy(g["dct_variance64"]), tmp_path / "dct_variance.pt")
+    net = _hip_net(g, dev, "hip")
+    B, S = 3, 64
+    kw = _base_kwargs(tmp_path, {})
+
+    def batch(seed):
+        ops, ys, noise = [], [], []
+        for b in range(B):
+            op = get_operator(name="super_resolution", device=dev, sigma_s=0.1, scale_factor=4, in_shape=(1, 3, S, S))
+            op.ctx_slot = b
+            ops.append(op)
+            x0 = inputs.smooth_image(S, seed + b).to(dev)
+            ys.append(op.forward(x0, noiseless=True))
+            noise.append(inputs.randn((1, 3, S, S), seed + 10 + b, torch.float32))
+        with torch.cuda.stream(side):
+            out = conditional_sampler_batched(net, torch.cat(noise).to(dev), ys, ops, num_steps=4, sigma_min=0.002,
+                                              sigma_max=80, rho=7, solver="heun", **kw)
+        torch.cuda.synchronize()
+        return out
+
+    side = torch.cuda.Stream()
+    streams_seen = []
+    for it in range(5):
+        batch(100 * it)
+        import free_hunch_amd.sampler as smp
+        streams_seen.append(tuple(smp._image_stream(0, b, dev).cuda_stream for b in range(B)))
+        if it == 2:
+            allocs, reserved = torch.cuda.memory_stats()["num_device_alloc"], torch.cuda.memory_reserved()
+    assert len(set(streams_seen)) == 1  # the same three streams every batch
+    assert torch.cuda.memory_stats()["num_device_alloc"] == allocs and torch.cuda.memory_reserved() == reserved
