@@ -403,6 +403,11 @@ class BFGSOnlineUpdate(ConditioningMechanism):
             p_y_xt_grad = cv * self.cond_scaling / sig2
             rec["branch"] = "cov"
         x_0_mean_new = m_det + p_y_xt_grad * sig2
+        self._finish_record(x_0_mean_new, x_det, m_det, s)
+        return x_0_mean_new
+
+    def _finish_record(self, x_0_mean_new, x_det, m_det, s):
+        cm, rec = self.covariance_model, self._rec
         rec["k"], rec["sigma"] = cm.k, s
         if os.environ.get("FH_TRACE_SUMS"):  # debugging aid: costs a device sync per call
             rec["out_sum"] = float(x_0_mean_new.double().sum())
@@ -410,7 +415,21 @@ class BFGSOnlineUpdate(ConditioningMechanism):
         self.sigmas.append(s)
         self.xs.append(x_det)
         self.denoiser_means.append(m_det)
-        return x_0_mean_new
+
+    @staticmethod
+    def fh_finish_batched(mechs, g, x_det, m_det, sigma, s, branch, cov_all=None):
+        """`fh_finish` of a lock-step batch whose images all take the same branch and share `cond_scaling`: the three or four
+        elementwise operations run once over [B,3,S,S] instead of once per image (the same arithmetic per element), the
+        per-image bookkeeping stays on the host.  `s` = float(sigma) (no device read-back), `branch` in {"vjp", "cov"},
+        `cov_all` = C . mat of the whole batch for the "cov" branch.  Returns x0_mean_new [B,3,S,S]."""
+        cs = mechs[0].cond_scaling
+        sig2 = torch.as_tensor(sigma, dtype=F64, device=m_det.device).pow(2)
+        p = g * cs if branch == "vjp" else cov_all * cs / sig2
+        out = m_det + p * sig2
+        for b, mm in enumerate(mechs):
+            mm._rec["branch"] = branch
+            mm._finish_record(out[b:b + 1], x_det[b:b + 1], m_det[b:b + 1], s)
+        return out
 
 
 

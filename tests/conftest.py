@@ -30,3 +30,17 @@ def gold():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_rngs(request):
+    """The reference's mask generator and noise models draw from the GLOBAL numpy / torch generators (measurements.py:244-290),
+    and so do their mirrors here: without a seed every process (and every test order) gets other inpainting masks, and a test
+    whose bound is tight for one mask in a hundred fails once in a hundred runs.  Every test starts from a seed derived from
+    its own node id."""
+    import zlib
+
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    np.random.seed(seed)
+    torch.manual_seed(seed)
