@@ -66,8 +66,11 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     onto 4 hardware queues and the small kernels sat behind convolutions of the other group in the same queue.  Since the
     updates and the CG of a group are single batched launch sequences on the group's own stream (round 3), two groups mean two
     streams: measured 3.43 s vs 3.82 s per batch of 8 (+11 %) on runs of a few batches; four groups of two images lose again
-    (UNet at batch 2).  On a SUSTAINED run (20 steps, the chip at its power limit) the overlap buys nothing: 2.200 vs 2.195
-    images/s - the convolutions slow down by what the overlap gains - so one group stays the default."""
+    (UNet at batch 2).  Earlier in round 3 a SUSTAINED run (20 steps) showed nothing (2.200 vs 2.195 images/s), which was read
+    as the power limit; it was the device-memory growth of fresh streams per batch, worse with more
+    streams.  With the streams kept across batches: 2.27 / 2.31 vs 2.10 / 2.17 images/s over 8 steps, alternating on one box,
+    and 2.35 vs 2.20 over 20 steps - two groups are the default (results bitwise equal to one group:
+    tests/test_timed_path.py::test_two_lockstep_groups_equal_one_group)."""
     from concurrent.futures import ThreadPoolExecutor
     from free_hunch_amd.measurements import get_operator
     from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
@@ -528,9 +531,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--groups", type=int, default=1,
-                    help="lock-step groups per GPU (2: the Free Hunch phase of one group overlaps the UNet phase of the other; "
-                         "+3-11 %% on runs of a few batches, nothing on a sustained, power-limited run - see run_batch)")
+    ap.add_argument("--groups", type=int, default=2,
+                    help="lock-step groups per GPU (default 2: the Free Hunch phase of one group of 4 overlaps the UNet phase of "
+                         "the other; 2.35 vs 2.20 images/s over 20 steps - see run_batch; 1 = one group of 8)")
     ap.add_argument("--arch", default="ffhq", choices=["ffhq", "imagenet"])
     ap.add_argument("--operator", default="gaussian_blur")
     ap.add_argument("--num-steps", type=int, default=30)
