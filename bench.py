@@ -73,7 +73,7 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     tests/test_timed_path.py::test_two_lockstep_groups_equal_one_group)."""
     from concurrent.futures import ThreadPoolExecutor
     from free_hunch_amd.measurements import get_operator
-    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_batched
+    from free_hunch_amd.sampler import StandardRGBEncoder, conditional_sampler_grouped
     enc = StandardRGBEncoder()
     S = images_u8.shape[-1]
     prof = os.environ.get("FH_PHASE_TIMES")
@@ -97,42 +97,10 @@ def run_batch(net, images_u8, seeds, operator_name, num_steps, solver, device, d
     if prof:
         torch.cuda.synchronize()
         print(f"[FH_PHASE_TIMES] run_batch setup (operators, measurements, noise): {time.perf_counter() - t_setup:.3f} s", flush=True)
-    groups = max(1, min(groups, B))
-    bounds = [round(g * B / groups) for g in range(groups + 1)]
-    main = torch.cuda.current_stream()
-    ready = torch.cuda.Event()
-    ready.record(main)
-    dev_index = device.index if device.index is not None else torch.cuda.current_device()
-
-    def run_group(g):
-        lo, hi = bounds[g], bounds[g + 1]
-        torch.cuda.set_device(dev_index)
-        stream = _GROUP_STREAMS.get((dev_index, g))  # one stream per group for the life of the process (the caching
-        if stream is None:                            # allocator reuses a stream's freed blocks only on that stream)
-            stream = _GROUP_STREAMS[(dev_index, g)] = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(stream):
-            stream.wait_event(ready)
-            x = conditional_sampler_batched(net, torch.cat(noises[lo:hi], 0).to(device), ys[lo:hi], ops[lo:hi],
-                                            num_steps=num_steps, sigma_min=0.002, sigma_max=80, rho=7, solver=solver,
-                                            slot_base=lo, exclusive_device=(groups == 1), **fh_kwargs(data_dir, solver))
-            out = enc.decode(x)
-            out.record_stream(main)
-            done = torch.cuda.Event()
-            done.record(stream)
-        return out, done, [sum(t["niter"] for t in m.trace) for m in conditional_sampler_batched.tls.mechanisms]
-
-    if groups == 1:
-        res = [run_group(0)]
-    else:
-        with ThreadPoolExecutor(max_workers=groups) as pool:
-            res = list(pool.map(run_group, range(groups)))
-    for _o, done, _n in res:
-        main.wait_event(done)
-    run_batch.cg_iters = [n for r in res for n in r[2]]
-    return torch.cat([r[0] for r in res], 0)
-
-
-_GROUP_STREAMS = {}
+    x = conditional_sampler_grouped(net, torch.cat(noises, 0).to(device), ys, ops, groups=groups, num_steps=num_steps,
+                                    sigma_min=0.002, sigma_max=80, rho=7, solver=solver, **fh_kwargs(data_dir, solver))
+    run_batch.cg_iters = [sum(t["niter"] for t in m.trace) for m in conditional_sampler_grouped.last_mechanisms]
+    return enc.decode(x)
 
 
 def _latest_profile(suffix):
